@@ -1,0 +1,173 @@
+/*
+ * nbody_mi355x.h -- C ABI of libnbody_mi355x.so, the MI355X (gfx950) all-pairs
+ * N-body hot path behind the particle_simulation.h API of CPestka/N-Body-Sim.
+ *
+ * Plain C: compiled by gcc/g++ on the host side (no HIP headers needed), by
+ * hipcc on the implementation side.  Only pointers, sizes and PODs cross the
+ * boundary; no exception does.  Every function returns NBODY_MI355X_OK (0) or
+ * a negative nbody_mi355x_status; the text of the last failure on the calling
+ * thread is nbody_mi355x_last_error().
+ *
+ * Citations "ref:" are file:line into the reference's src/ directory and name
+ * the reference interface the entry point replaces.
+ *
+ * Two levels:
+ *   (1) stateless device-pointer entry points (nbody_mi355x_step_f64 ...):
+ *       the hot path itself on caller-owned device memory and a caller-owned
+ *       HIP stream.  This is what a multi-process (one rank per GPU) driver
+ *       uses, with its own collective between steps.
+ *   (2) the handle API (nbody_mi355x_create ... _destroy): host pointers in the
+ *       reference's own record layouts in, snapshots out; this is what
+ *       ParticleSimulation::SimulateMI355X() binds.
+ */
+#ifndef NBODY_MI355X_H_
+#define NBODY_MI355X_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  NBODY_MI355X_OK = 0,
+  NBODY_MI355X_ERR_INVALID = -1,  /* bad argument (null, size, alignment)        */
+  NBODY_MI355X_ERR_ALLOC = -2,    /* ref: "Failed memory allocation on device."   */
+  NBODY_MI355X_ERR_H2D = -3,      /* ref: "Failed memory copy to device."         */
+  NBODY_MI355X_ERR_D2H = -4,      /* ref: "Failed to copy results to host."       */
+  NBODY_MI355X_ERR_FREE = -5,     /* ref: "Failed to free device memory."         */
+  NBODY_MI355X_ERR_LAUNCH = -6,   /* kernel launch / execution error (the reference
+                                     never checks this, particle_simulation_GPU.cu:149-155) */
+  NBODY_MI355X_ERR_NO_DEVICE = -7 /* no usable HIP device                         */
+} nbody_mi355x_status;
+
+/* The simulator's gravitational constant, ref: particle_simulation.h:713 and
+ * particle_simulation_GPU.cu:75 (6.7430e-11, not 6.67430e-11). */
+#define NBODY_MI355X_G_REFERENCE 6.7430e-11
+
+/* Arithmetic of the force accumulation. */
+#define NBODY_MI355X_FP64 0 /* everything in double (parity path)                */
+#define NBODY_MI355X_FP32 1 /* separations in double, r^-3 and sums in float      */
+
+/* Tile width of the j loop; shard_slots must be a multiple of it. */
+#define NBODY_MI355X_TILE 256
+
+const char* nbody_mi355x_last_error(void);
+int nbody_mi355x_device_count(int* count);
+
+/* ------------------------------------------------------------------ level 1
+ *
+ * Device layout ("slab" layout).  Bodies live in num_shards slabs of
+ * shard_slots slots each (slot g = shard * shard_slots + offset); slab s keeps
+ * its coordinates as three contiguous runs
+ *     pos[s*3*shard_slots + 0*shard_slots + offset]  x
+ *     pos[s*3*shard_slots + 1*shard_slots + offset]  y
+ *     pos[s*3*shard_slots + 2*shard_slots + offset]  z
+ * so that one slab is one contiguous block (one in-place all-gather moves
+ * every rank's updated coordinates), and mass[g] is a flat array of
+ * num_shards*shard_slots doubles.  Slots past the real bodies of a slab are
+ * padding: mass 0, position 0, never written.  A single-GPU run is
+ * num_shards = 1.  vel, acc_in, acc_out hold the calling rank's own slab only:
+ * [3][shard_slots].
+ */
+typedef struct {
+  const double* pos_cur;  /* all slabs, read                                   */
+  double* pos_next;       /* all slabs; only own slab's real slots are written */
+  const double* mass;     /* all slabs                                         */
+  double* vel;            /* own slab, updated in place                        */
+  const double* acc_in;   /* own slab partial sums to start from, or NULL (0)  */
+  double* acc_out;        /* if not NULL: store the raw sums (no G) here and
+                             do NOT integrate (first half of a split step)    */
+  double* snapshot;       /* if not NULL: DeviceOutputParticle<double>
+                             [own_count] = {r', v', a*G} (ref:
+                             particle_simulation.h:26-31), device memory      */
+  int64_t shard_slots;    /* multiple of NBODY_MI355X_TILE                     */
+  int32_t num_shards;
+  int32_t own_shard;
+  int64_t own_count;      /* real bodies in the own slab (<= shard_slots)      */
+  /* j slots to interact with: [j0_begin, j0_end) then [j1_begin, j1_end);
+   * begins must be multiples of NBODY_MI355X_TILE; an empty range has
+   * begin == end.  A full step is {0, num_shards*shard_slots, 0, 0}. */
+  int64_t j0_begin, j0_end, j1_begin, j1_end;
+  double dt;              /* ref: stepsize_                                    */
+  double G;               /* NBODY_MI355X_G_REFERENCE for parity               */
+  double eps2;            /* softening^2; 0 = reference semantics: pairs with
+                             r^2 == 0 contribute nothing (ref:
+                             particle_simulation.h:269)                        */
+  int32_t precision;      /* NBODY_MI355X_FP64 / _FP32                         */
+  int32_t variant;        /* 0 = default kernel choice; >0 selects a specific
+                             kernel build (tuning / A-B benchmarking)          */
+} nbody_mi355x_step_args;
+
+/* One small step (or one half of a split one) for the own slab's bodies:
+ * a_i = sum_j m_j (r_j - r_i) / |r_j - r_i|^3 over the j ranges, then
+ * v' = v + (dt*a)*G, r' = r + dt*v (old v), optional snapshot.
+ * Replaces ref: MakeSmallStepDevice, particle_simulation_GPU.cu:60-142 (same
+ * maths as MakeSmallStep, particle_simulation.h:248-322).  Asynchronous on
+ * `stream` (a hipStream_t, NULL = the default stream). */
+int nbody_mi355x_step_f64(const nbody_mi355x_step_args* args, void* stream);
+
+/* Particle<double>[count] AoS {r[3], v[3]} (ref: particle_simulation.h:20-24)
+ * on the device -> own slab's pos (x,y,z runs) + vel, and back.  These are the
+ * layout converters either side of the step kernel. */
+int nbody_mi355x_pack_f64(const double* particles_aos, int64_t count, double* pos_slab,
+                          double* vel, int64_t shard_slots, void* stream);
+int nbody_mi355x_unpack_f64(const double* pos_slab, const double* vel, int64_t count,
+                            int64_t shard_slots, double* particles_aos, void* stream);
+
+/* Energy diagnostic (the reference has none; SURVEY 8d correctness gate):
+ * ke = sum 1/2 m v^2 over the own slab, pe = -G * sum over own i, all j > i of
+ * m_i m_j / r_ij (coincident pairs skipped).  scratch: device, >= 2 doubles
+ * per 256 own slots + 2; result[2] = {ke, pe}: device.  Asynchronous. */
+int nbody_mi355x_energy_f64(const double* pos, const double* mass, const double* vel,
+                            int64_t shard_slots, int32_t num_shards, int32_t own_shard,
+                            int64_t own_count, double G, double* scratch, double* result,
+                            void* stream);
+
+/* ------------------------------------------------------------------ level 2 */
+typedef struct nbody_mi355x_sim nbody_mi355x_sim; /* opaque */
+
+typedef struct {
+  int64_t num_particles; /* ref: num_particles_                                */
+  double stepsize;       /* ref: stepsize_                                     */
+  double G;              /* 0 -> NBODY_MI355X_G_REFERENCE                      */
+  double eps2;           /* 0 = reference semantics                            */
+  int32_t precision;     /* NBODY_MI355X_FP64 / _FP32                          */
+  int32_t device;        /* HIP device ordinal                                 */
+  int32_t host_is_float; /* 0: host records are double (ParticleSimulation<double,W>),
+                            1: float (ParticleSimulation<float,W>)             */
+  int32_t variant;       /* as in nbody_mi355x_step_args                       */
+} nbody_mi355x_config;
+
+/* ref: AllocateDeviceMemory, particle_simulation_GPU.cu:13-35 (4 cudaMalloc). */
+int nbody_mi355x_create(const nbody_mi355x_config* cfg, nbody_mi355x_sim** sim);
+/* ref: FreeDeviceMemory, particle_simulation_GPU.cu:216-231. */
+int nbody_mi355x_destroy(nbody_mi355x_sim* sim);
+/* ref: CopyDataToDevice, particle_simulation_GPU.cu:40-54.  particles =
+ * Particle<T>[N], mass = T[N], borrowed for the duration of the call. */
+int nbody_mi355x_upload(nbody_mi355x_sim* sim, const void* particles, const void* mass);
+/* ref: MakeBigStepDevice, particle_simulation_GPU.cu:145-178, plus that big
+ * step's share of CopyResultsToHost (:198-211): runs `substeps` small steps
+ * back to back on the device with no host synchronisation in between; if
+ * snapshot_out is not NULL the LAST small step also writes
+ * DeviceOutputParticle<T>[N] = {r, v, a*G} there (host memory).  Blocks until
+ * the big step is complete (the reference's per-big-step timing needs that). */
+int nbody_mi355x_run(nbody_mi355x_sim* sim, int64_t substeps, void* snapshot_out);
+/* Current state back as Particle<T>[N]. */
+int nbody_mi355x_download(nbody_mi355x_sim* sim, void* particles);
+/* Total kinetic and potential energy of the current state. */
+int nbody_mi355x_energy(nbody_mi355x_sim* sim, double* ke, double* pe);
+/* Device time (hipEvent) of the kernels of the last nbody_mi355x_run, seconds. */
+int nbody_mi355x_last_run_seconds(nbody_mi355x_sim* sim, double* seconds);
+
+/* --------------------------------------------------- initial conditions (host)
+ * Synthetic scenes with an in-library portable RNG (splitmix64-seeded
+ * xoshiro256**), SURVEY 8d configs 3-5.  particles: Particle<double>[n],
+ * mass: double[n].  Units: G*M_total = 1 with the G passed in. */
+int nbody_mi355x_ic_plummer(int64_t n, uint64_t seed, double G, double* particles, double* mass);
+int nbody_mi355x_ic_uniform_cube(int64_t n, uint64_t seed, double G, double* particles, double* mass);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NBODY_MI355X_H_ */

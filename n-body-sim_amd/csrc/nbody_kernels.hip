@@ -1,0 +1,504 @@
+// nbody_kernels.hip -- gfx950 (MI355X) kernels of the all-pairs hot path and the
+// stateless (device-pointer) half of the C ABI declared in include/nbody_mi355x.h.
+//
+// What is computed is the reference's MakeSmallStep (particle_simulation.h:248-322;
+// CUDA twin particle_simulation_GPU.cu:60-142):
+//     a_i = sum_j m_j (r_j - r_i) / |r_j - r_i|^3        (pairs with r^2 == 0 skipped)
+//     v_i' = v_i + (dt * a_i) * G ;  r_i' = r_i + dt * v_i (old v)
+// How it is computed is MI355X-first and shares nothing with the reference's
+// one-thread-per-body global-memory kernel:
+//   * slab SoA layout in HBM (see the header), coalesced 8-byte loads;
+//   * a 256-thread workgroup owns 256*IPT i-bodies held in registers, walks
+//     the j bodies in tiles of 256 staged through LDS as {x,y,z,m} records
+//     (register-prefetched, two LDS buffers, one barrier per tile); every lane
+//     reads the same j record per step, i.e. conflict-free LDS broadcasts
+//     (2 x ds_read_b128 per j, amortised over IPT interactions);
+//   * r^-3 from v_rsq_f64 plus a folded series correction, no division, no
+//     sqrt, no branch: the r^2 == 0 rule is kept exactly by seeding the r^2 FMA
+//     chain with 2^-600 (see pair_f64), which costs no instruction;
+//   * the Euler update and the optional snapshot are fused into the epilogue.
+// FP64 vector FMA is the bounding unit (no MFMA: this is not a contraction).
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+
+#include "nbody_internal.h"
+
+namespace {
+
+constexpr int kTile = NBODY_MI355X_TILE;  // threads per workgroup == j bodies per tile
+
+struct alignas(32) JBody {
+  double x, y, z, m;
+};
+
+// 2^-600.  With eps2 == 0 the kernel adds this to r^2 inside the first FMA of
+// the r^2 chain.  For any pair a simulation can hold apart (r > 1e-82 in the
+// unit of length) r^2 + 2^-600 rounds to r^2, so the value is bit-for-bit the
+// unsoftened one; for r^2 == 0 (i == j, or coincident bodies) it makes
+// rsq finite (2^300), m * 2^900 stays finite for m < 2^124, and the pair
+// contributes s * 0 = 0: exactly the reference's `if (r_squared != 0)`
+// (particle_simulation.h:269) without a compare or a select.
+constexpr double kTinyR2 = 0x1p-600;
+
+// One interaction in double: 16 FP64 VALU operations + v_rsq_f64:
+//   3 sub, 3 fma (r^2), rsq, 7 for m * r^-3 (below), 3 fma (accumulate).
+// y0 = v_rsq_f64(r2) is only a seed (the ISA promises about 2^-23 relative).  With
+// u = y0^2 and e = 1 - r2*u (one FMA, so e carries just u's rounding) the exact value is
+//   r2^(-3/2) = y0^3 * (1 - e)^(-3/2) = y0^3 * (1 + 3/2 e + 15/8 e^2 + 35/16 e^3 ...)
+// and the series is cut after e^2: the truncation error is 2.2 |e|^3, below
+// 2^-53 for any seed better than 2^-19.  c15/c1875 are 1.5 and 1.875 held in
+// registers by the caller (neither is an inline constant of the ISA; as literals
+// they cost two v_mov per interaction).
+__device__ __forceinline__ void pair_f64(double xi, double yi, double zi, double xj, double yj,
+                                         double zj, double mj, double eps2, double c15,
+                                         double c1875, double& ax, double& ay, double& az) {
+  const double dx = xj - xi;
+  const double dy = yj - yi;
+  const double dz = zj - zi;
+  const double r2 = __builtin_fma(dz, dz, __builtin_fma(dy, dy, __builtin_fma(dx, dx, eps2)));
+  const double y0 = __builtin_amdgcn_rsq(r2);
+  const double u = y0 * y0;
+  const double e = __builtin_fma(-r2, u, 1.0);
+  const double q = mj * y0;
+  const double w = q * u;                       // m * y0^3
+  const double p = __builtin_fma(e, c1875, c15);
+  const double we = w * e;
+  const double s = __builtin_fma(we, p, w);     // m * r^-3
+  ax = __builtin_fma(s, dx, ax);
+  ay = __builtin_fma(s, dy, ay);
+  az = __builtin_fma(s, dz, az);
+}
+
+// Mixed variant: separations and r^2 in double (so that close pairs of bodies
+// far from the origin do not cancel catastrophically), r^-3 and the running
+// sums in float.  v_rsq_f32 is accurate to ~1 ulp, no correction step.
+__device__ __forceinline__ void pair_f32(double xi, double yi, double zi, double xj, double yj,
+                                         double zj, float mj, double eps2, float& ax, float& ay,
+                                         float& az) {
+  const float dx = static_cast<float>(xj - xi);
+  const float dy = static_cast<float>(yj - yi);
+  const float dz = static_cast<float>(zj - zi);
+  const float r2 =
+      __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, __builtin_fmaf(dx, dx, static_cast<float>(eps2))));
+  const float y0 = __builtin_amdgcn_rsqf(r2);
+  const float s = (mj * y0) * (y0 * y0);
+  ax = __builtin_fmaf(s, dx, ax);
+  ay = __builtin_fmaf(s, dy, ay);
+  az = __builtin_fmaf(s, dz, az);
+}
+
+template <typename Acc>
+struct AccOps;
+template <>
+struct AccOps<double> {
+  static __device__ __forceinline__ void pair(double xi, double yi, double zi, const JBody& b,
+                                              double eps2, double c15, double c1875, double& ax,
+                                              double& ay, double& az) {
+    pair_f64(xi, yi, zi, b.x, b.y, b.z, b.m, eps2, c15, c1875, ax, ay, az);
+  }
+};
+template <>
+struct AccOps<float> {
+  static __device__ __forceinline__ void pair(double xi, double yi, double zi, const JBody& b,
+                                              double eps2, double, double, float& ax, float& ay,
+                                              float& az) {
+    pair_f32(xi, yi, zi, b.x, b.y, b.z, static_cast<float>(b.m), eps2, ax, ay, az);
+  }
+};
+
+// Fetch the j body that thread `tid` stages for the tile starting at slot jt.
+__device__ __forceinline__ JBody load_j(const nbody_mi355x_step_args& a, int64_t jt, int64_t jend,
+                                        int tid) {
+  JBody b;
+  const int64_t shard = jt / a.shard_slots;  // wave-uniform: a tile never straddles slabs
+  const int64_t off = jt - shard * a.shard_slots + tid;
+  const double* base = a.pos_cur + shard * 3 * a.shard_slots + off;
+  const bool ok = (jt + tid) < jend;
+  // Slots in [jend, tile end) still lie inside the slab allocation (shard_slots is a
+  // multiple of the tile), so the loads are in bounds; they are masked to a massless
+  // body at the origin, which contributes exactly zero.
+  const double x = base[0];
+  const double y = base[a.shard_slots];
+  const double z = base[2 * a.shard_slots];
+  const double m = a.mass[jt + tid];
+  b.x = ok ? x : 0.0;
+  b.y = ok ? y : 0.0;
+  b.z = ok ? z : 0.0;
+  b.m = ok ? m : 0.0;
+  return b;
+}
+
+template <int IPT, typename Acc, int UNROLL>
+__global__ __launch_bounds__(kTile) void step_kernel(const nbody_mi355x_step_args a) {
+  __shared__ JBody tile[2][kTile];
+  const int tid = threadIdx.x;
+  const int64_t S = a.shard_slots;
+  const double eps2 = (a.eps2 > 0.0) ? a.eps2 : kTinyR2;
+  double c15 = 1.5, c1875 = 1.875;  // opaque to the optimiser: stay in VGPRs (see pair_f64)
+  asm volatile("" : "+v"(c15), "+v"(c1875));
+
+  // own bodies: local slot li[k] = block*256*IPT + k*256 + tid (coalesced per k)
+  const int64_t li0 = static_cast<int64_t>(blockIdx.x) * (kTile * IPT) + tid;
+  const double* own = a.pos_cur + static_cast<int64_t>(a.own_shard) * 3 * S;
+  double xi[IPT], yi[IPT], zi[IPT];
+  Acc ax[IPT], ay[IPT], az[IPT];
+#pragma unroll
+  for (int k = 0; k < IPT; k++) {
+    const int64_t li = li0 + k * kTile;
+    // lanes past the slab end clamp their loads (results are discarded below)
+    const int64_t lc = li < S ? li : S - 1;
+    xi[k] = own[lc];
+    yi[k] = own[S + lc];
+    zi[k] = own[2 * S + lc];
+    if (a.acc_in != nullptr) {
+      ax[k] = static_cast<Acc>(a.acc_in[lc]);
+      ay[k] = static_cast<Acc>(a.acc_in[S + lc]);
+      az[k] = static_cast<Acc>(a.acc_in[2 * S + lc]);
+    } else {
+      ax[k] = ay[k] = az[k] = Acc(0);
+    }
+  }
+
+  const int64_t t0 = (a.j0_end - a.j0_begin + kTile - 1) / kTile;
+  const int64_t t1 = (a.j1_end - a.j1_begin + kTile - 1) / kTile;
+  const int64_t ntiles = t0 + t1;
+
+  auto tile_start = [&](int64_t t, int64_t& jend) -> int64_t {
+    if (t < t0) {
+      jend = a.j0_end;
+      return a.j0_begin + t * kTile;
+    }
+    jend = a.j1_end;
+    return a.j1_begin + (t - t0) * kTile;
+  };
+
+  if (ntiles > 0) {
+    int64_t jend;
+    int64_t jt = tile_start(0, jend);
+    tile[0][tid] = load_j(a, jt, jend, tid);
+    __syncthreads();
+    for (int64_t t = 0; t < ntiles; t++) {
+      const int buf = static_cast<int>(t & 1);
+      JBody nxt;
+      const bool more = (t + 1) < ntiles;
+      if (more) {
+        jt = tile_start(t + 1, jend);
+        nxt = load_j(a, jt, jend, tid);  // in flight while this tile is computed
+      }
+#pragma unroll UNROLL
+      for (int jj = 0; jj < kTile; jj++) {
+        const JBody b = tile[buf][jj];  // same address in every lane: LDS broadcast
+#pragma unroll
+        for (int k = 0; k < IPT; k++) AccOps<Acc>::pair(xi[k], yi[k], zi[k], b, eps2, c15, c1875, ax[k], ay[k], az[k]);
+      }
+      if (more) tile[buf ^ 1][tid] = nxt;  // buf^1 was last read before the previous barrier
+      __syncthreads();
+    }
+  }
+
+#pragma unroll
+  for (int k = 0; k < IPT; k++) {
+    const int64_t li = li0 + k * kTile;
+    if (li >= a.own_count) continue;
+    const double axd = static_cast<double>(ax[k]);
+    const double ayd = static_cast<double>(ay[k]);
+    const double azd = static_cast<double>(az[k]);
+    if (a.acc_out != nullptr) {  // first half of a split step: hand the raw sums on
+      a.acc_out[li] = axd;
+      a.acc_out[S + li] = ayd;
+      a.acc_out[2 * S + li] = azd;
+      continue;
+    }
+    // ref: particle_simulation.h:288-300.  `v + (dt*a)*G` and `r + dt*v` are each one
+    // FMA, which is also what GCC -O3 -mfma makes of the reference's expressions.
+    const double vx = a.vel[li], vy = a.vel[S + li], vz = a.vel[2 * S + li];
+    const double nvx = __builtin_fma(a.dt * axd, a.G, vx);
+    const double nvy = __builtin_fma(a.dt * ayd, a.G, vy);
+    const double nvz = __builtin_fma(a.dt * azd, a.G, vz);
+    const double nx = __builtin_fma(a.dt, vx, xi[k]);
+    const double ny = __builtin_fma(a.dt, vy, yi[k]);
+    const double nz = __builtin_fma(a.dt, vz, zi[k]);
+    a.vel[li] = nvx;
+    a.vel[S + li] = nvy;
+    a.vel[2 * S + li] = nvz;
+    double* nown = a.pos_next + static_cast<int64_t>(a.own_shard) * 3 * S;
+    nown[li] = nx;
+    nown[S + li] = ny;
+    nown[2 * S + li] = nz;
+    if (a.snapshot != nullptr) {  // ref: particle_simulation.h:304-315 / .cu:127-141
+      double* o = a.snapshot + 9 * li;
+      o[0] = nx; o[1] = ny; o[2] = nz;
+      o[3] = nvx; o[4] = nvy; o[5] = nvz;
+      o[6] = axd * a.G; o[7] = ayd * a.G; o[8] = azd * a.G;
+    }
+  }
+}
+
+// ------------------------------------------------------------ layout converters
+__global__ void pack_kernel(const double* __restrict__ aos, int64_t count, double* __restrict__ pos,
+                            double* __restrict__ vel, int64_t S) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  const double* p = aos + 6 * i;
+  pos[i] = p[0]; pos[S + i] = p[1]; pos[2 * S + i] = p[2];
+  vel[i] = p[3]; vel[S + i] = p[4]; vel[2 * S + i] = p[5];
+}
+
+__global__ void unpack_kernel(const double* __restrict__ pos, const double* __restrict__ vel,
+                              int64_t count, int64_t S, double* __restrict__ aos) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  double* p = aos + 6 * i;
+  p[0] = pos[i]; p[1] = pos[S + i]; p[2] = pos[2 * S + i];
+  p[3] = vel[i]; p[4] = vel[S + i]; p[5] = vel[2 * S + i];
+}
+
+// ------------------------------------------------------------ energy diagnostic
+__device__ __forceinline__ double block_sum(double v, double* red) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  __syncthreads();
+  if (l == 0) red[w] = v;
+  __syncthreads();
+  double s = 0.0;
+  if (threadIdx.x == 0)
+    for (int i = 0; i < kTile / 64; i++) s += red[i];
+  return s;  // valid in thread 0
+}
+
+__global__ __launch_bounds__(kTile) void energy_partial_kernel(
+    const double* __restrict__ pos, const double* __restrict__ mass, const double* __restrict__ vel,
+    int64_t S, int num_shards, int own_shard, int64_t own_count, double G,
+    double* __restrict__ scratch) {
+  __shared__ JBody tile[kTile];
+  __shared__ double red[kTile / 64];
+  const int tid = threadIdx.x;
+  const int64_t li = static_cast<int64_t>(blockIdx.x) * kTile + tid;
+  const int64_t lc = li < S ? li : S - 1;
+  const bool real = li < own_count;
+  const double* own = pos + static_cast<int64_t>(own_shard) * 3 * S;
+  const double xi = own[lc], yi = own[S + lc], zi = own[2 * S + lc];
+  const int64_t gi = static_cast<int64_t>(own_shard) * S + lc;
+  const double mi = real ? mass[gi] : 0.0;
+  double ke = 0.0;
+  if (real) {
+    const double vx = vel[lc], vy = vel[S + lc], vz = vel[2 * S + lc];
+    ke = 0.5 * mi * (vx * vx + vy * vy + vz * vz);
+  }
+  // sum over ALL j != i of m_j / r_ij; each unordered pair is met twice across the
+  // grid, hence the factor 1/2 below.
+  double phi = 0.0;
+  const int64_t total = static_cast<int64_t>(num_shards) * S;
+  for (int64_t jt = 0; jt < total; jt += kTile) {
+    const int64_t shard = jt / S;
+    const int64_t off = jt - shard * S + tid;
+    const double* base = pos + shard * 3 * S + off;
+    JBody b;
+    b.x = base[0]; b.y = base[S]; b.z = base[2 * S]; b.m = mass[jt + tid];
+    __syncthreads();
+    tile[tid] = b;
+    __syncthreads();
+#pragma unroll 4
+    for (int jj = 0; jj < kTile; jj++) {
+      const JBody o = tile[jj];
+      const double dx = o.x - xi, dy = o.y - yi, dz = o.z - zi;
+      const double r2 = dx * dx + dy * dy + dz * dz;
+      phi += (r2 != 0.0) ? o.m / sqrt(r2) : 0.0;
+    }
+  }
+  const double pe = -0.5 * G * mi * phi;
+  const double bke = block_sum(ke, red);
+  const double bpe = block_sum(pe, red);
+  if (tid == 0) {
+    scratch[2 * blockIdx.x] = bke;
+    scratch[2 * blockIdx.x + 1] = bpe;
+  }
+}
+
+__global__ __launch_bounds__(kTile) void energy_final_kernel(const double* __restrict__ scratch,
+                                                             int64_t nblocks,
+                                                             double* __restrict__ result) {
+  __shared__ double red[kTile / 64];
+  double ke = 0.0, pe = 0.0;
+  for (int64_t b = threadIdx.x; b < nblocks; b += kTile) {
+    ke += scratch[2 * b];
+    pe += scratch[2 * b + 1];
+  }
+  const double ske = block_sum(ke, red);
+  const double spe = block_sum(pe, red);
+  if (threadIdx.x == 0) {
+    result[0] = ske;
+    result[1] = spe;
+  }
+}
+
+template <int IPT, typename Acc, int UNROLL>
+hipError_t launch_step(const nbody_mi355x_step_args& a, hipStream_t stream) {
+  const int64_t per_block = static_cast<int64_t>(kTile) * IPT;
+  const int64_t blocks = (a.own_count + per_block - 1) / per_block;
+  if (blocks <= 0) return hipSuccess;
+  hipLaunchKernelGGL((step_kernel<IPT, Acc, UNROLL>), dim3(static_cast<unsigned>(blocks)), dim3(kTile),
+                     0, stream, a);
+  return hipGetLastError();
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------ error text
+namespace nbody_internal {
+thread_local char g_last_error[512] = "";
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_last_error, sizeof g_last_error, fmt, ap);
+  va_end(ap);
+}
+}  // namespace nbody_internal
+
+using nbody_internal::set_error;
+
+extern "C" const char* nbody_mi355x_last_error(void) { return nbody_internal::g_last_error; }
+
+extern "C" int nbody_mi355x_device_count(int* count) {
+  if (!count) return NBODY_MI355X_ERR_INVALID;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    *count = 0;
+    set_error("hipGetDeviceCount: %s", hipGetErrorString(e));
+    return NBODY_MI355X_ERR_NO_DEVICE;
+  }
+  *count = n;
+  return NBODY_MI355X_OK;
+}
+
+// Host-side shape checks: everything the kernel's indexing assumes is verified
+// here, before any launch.
+static int check_step_args(const nbody_mi355x_step_args* a) {
+  if (!a) { set_error("step: null args"); return NBODY_MI355X_ERR_INVALID; }
+  if (!a->pos_cur || !a->mass) { set_error("step: null pos_cur/mass"); return NBODY_MI355X_ERR_INVALID; }
+  if (a->shard_slots <= 0 || a->shard_slots % kTile != 0) {
+    set_error("step: shard_slots=%lld must be a positive multiple of %d", (long long)a->shard_slots, kTile);
+    return NBODY_MI355X_ERR_INVALID;
+  }
+  if (a->num_shards <= 0 || a->own_shard < 0 || a->own_shard >= a->num_shards) {
+    set_error("step: own_shard=%d outside [0,%d)", a->own_shard, a->num_shards);
+    return NBODY_MI355X_ERR_INVALID;
+  }
+  if (a->own_count < 0 || a->own_count > a->shard_slots) {
+    set_error("step: own_count=%lld outside [0,%lld]", (long long)a->own_count, (long long)a->shard_slots);
+    return NBODY_MI355X_ERR_INVALID;
+  }
+  const int64_t total = a->shard_slots * a->num_shards;
+  const int64_t r[4] = {a->j0_begin, a->j0_end, a->j1_begin, a->j1_end};
+  for (int k = 0; k < 2; k++) {
+    const int64_t b = r[2 * k], e = r[2 * k + 1];
+    if (b < 0 || e < b || e > total || b % kTile != 0) {
+      set_error("step: j range %d = [%lld,%lld) invalid (total %lld, begin must be a multiple of %d)", k,
+                (long long)b, (long long)e, (long long)total, kTile);
+      return NBODY_MI355X_ERR_INVALID;
+    }
+  }
+  if (a->acc_out == nullptr && (!a->pos_next || !a->vel)) {
+    set_error("step: integrating step needs pos_next and vel");
+    return NBODY_MI355X_ERR_INVALID;
+  }
+  if (a->pos_next == a->pos_cur && a->acc_out == nullptr) {
+    set_error("step: pos_next must not alias pos_cur");
+    return NBODY_MI355X_ERR_INVALID;
+  }
+  if (!(a->eps2 >= 0.0)) { set_error("step: eps2 must be >= 0"); return NBODY_MI355X_ERR_INVALID; }
+  if (a->precision != NBODY_MI355X_FP64 && a->precision != NBODY_MI355X_FP32) {
+    set_error("step: unknown precision %d", a->precision);
+    return NBODY_MI355X_ERR_INVALID;
+  }
+  return NBODY_MI355X_OK;
+}
+
+extern "C" int nbody_mi355x_step_f64(const nbody_mi355x_step_args* args, void* stream) {
+  int rc = check_step_args(args);
+  if (rc != NBODY_MI355X_OK) return rc;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipError_t e;
+  if (args->precision == NBODY_MI355X_FP32) {
+    switch (args->variant) {
+      case 1: e = launch_step<1, float, 8>(*args, s); break;
+      case 4: e = launch_step<4, float, 4>(*args, s); break;
+      default: e = launch_step<2, float, 8>(*args, s); break;
+    }
+  } else {
+    switch (args->variant) {
+      case 1: e = launch_step<1, double, 8>(*args, s); break;
+      case 2: e = launch_step<2, double, 4>(*args, s); break;
+      case 3: e = launch_step<1, double, 4>(*args, s); break;
+      case 4: e = launch_step<4, double, 2>(*args, s); break;
+      case 5: e = launch_step<2, double, 8>(*args, s); break;
+      default:
+        // enough workgroups to give every SIMD >= 2 waves with 2 bodies per lane?
+        if (args->own_count >= 2 * 256 * 4 * 2 * 64) e = launch_step<2, double, 4>(*args, s);
+        else e = launch_step<1, double, 8>(*args, s);
+        break;
+    }
+  }
+  if (e != hipSuccess) {
+    set_error("step launch: %s", hipGetErrorString(e));
+    return NBODY_MI355X_ERR_LAUNCH;
+  }
+  return NBODY_MI355X_OK;
+}
+
+extern "C" int nbody_mi355x_pack_f64(const double* aos, int64_t count, double* pos_slab, double* vel,
+                                     int64_t shard_slots, void* stream) {
+  if (!aos || !pos_slab || !vel || count < 0 || count > shard_slots) {
+    set_error("pack: bad arguments");
+    return NBODY_MI355X_ERR_INVALID;
+  }
+  if (count == 0) return NBODY_MI355X_OK;
+  const unsigned blocks = static_cast<unsigned>((count + 255) / 256);
+  hipLaunchKernelGGL(pack_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), aos,
+                     count, pos_slab, vel, shard_slots);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { set_error("pack launch: %s", hipGetErrorString(e)); return NBODY_MI355X_ERR_LAUNCH; }
+  return NBODY_MI355X_OK;
+}
+
+extern "C" int nbody_mi355x_unpack_f64(const double* pos_slab, const double* vel, int64_t count,
+                                       int64_t shard_slots, double* aos, void* stream) {
+  if (!aos || !pos_slab || !vel || count < 0 || count > shard_slots) {
+    set_error("unpack: bad arguments");
+    return NBODY_MI355X_ERR_INVALID;
+  }
+  if (count == 0) return NBODY_MI355X_OK;
+  const unsigned blocks = static_cast<unsigned>((count + 255) / 256);
+  hipLaunchKernelGGL(unpack_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     pos_slab, vel, count, shard_slots, aos);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { set_error("unpack launch: %s", hipGetErrorString(e)); return NBODY_MI355X_ERR_LAUNCH; }
+  return NBODY_MI355X_OK;
+}
+
+extern "C" int nbody_mi355x_energy_f64(const double* pos, const double* mass, const double* vel,
+                                       int64_t shard_slots, int32_t num_shards, int32_t own_shard,
+                                       int64_t own_count, double G, double* scratch, double* result,
+                                       void* stream) {
+  if (!pos || !mass || !vel || !scratch || !result || shard_slots <= 0 || shard_slots % kTile != 0 ||
+      num_shards <= 0 || own_shard < 0 || own_shard >= num_shards || own_count < 0 ||
+      own_count > shard_slots) {
+    set_error("energy: bad arguments");
+    return NBODY_MI355X_ERR_INVALID;
+  }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int64_t blocks = (own_count + kTile - 1) / kTile;
+  if (blocks > 0) {
+    hipLaunchKernelGGL(energy_partial_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kTile), 0, s, pos,
+                       mass, vel, shard_slots, num_shards, own_shard, own_count, G, scratch);
+  }
+  hipLaunchKernelGGL(energy_final_kernel, dim3(1), dim3(kTile), 0, s, scratch, blocks, result);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { set_error("energy launch: %s", hipGetErrorString(e)); return NBODY_MI355X_ERR_LAUNCH; }
+  return NBODY_MI355X_OK;
+}

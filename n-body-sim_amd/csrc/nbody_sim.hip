@@ -1,0 +1,250 @@
+// nbody_sim.hip -- the handle half of the C ABI (include/nbody_mi355x.h, "level 2"):
+// what ParticleSimulation::SimulateMI355X() binds.  It mirrors the stage structure
+// of the reference's SimulateGPU() (particle_simulation_GPU.cu:277-303) --
+// allocate, copy in, big steps, copy out, free -- but owns one HIP stream, keeps
+// the whole substep loop of a big step on the device without host
+// synchronisation (the reference syncs after every substep, .cu:155), and
+// returns each big step's snapshot as soon as it exists instead of holding
+// 72*N*num_big_steps bytes on the device (.cu:29-30).
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "nbody_internal.h"
+
+using nbody_internal::set_error;
+
+struct nbody_mi355x_sim {
+  nbody_mi355x_config cfg{};
+  int64_t n = 0;      // real bodies
+  int64_t slots = 0;  // n rounded up to the tile
+  double* pos[2] = {nullptr, nullptr};  // [3][slots] each
+  double* vel = nullptr;                // [3][slots]
+  double* mass = nullptr;               // [slots]
+  double* aos = nullptr;                // staging: Particle<double>[n] / DeviceOutputParticle<double>[n]
+  double* scratch = nullptr;            // energy partials + result
+  int cur = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  double last_run_seconds = 0.0;
+  std::vector<double> host_tmp;  // float <-> double conversion of host records
+};
+
+namespace {
+
+#define HIP_TRY(expr, code, what)                                            \
+  do {                                                                       \
+    hipError_t e_ = (expr);                                                  \
+    if (e_ != hipSuccess) {                                                  \
+      (void)hipGetLastError();                                               \
+      set_error("%s: %s", what, hipGetErrorString(e_));                      \
+      return code;                                                           \
+    }                                                                        \
+  } while (0)
+
+int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
+
+int free_all(nbody_mi355x_sim* s) {
+  int rc = NBODY_MI355X_OK;
+  auto fr = [&](double*& p) {
+    if (p && hipFree(p) != hipSuccess) rc = NBODY_MI355X_ERR_FREE;
+    p = nullptr;
+  };
+  fr(s->pos[0]); fr(s->pos[1]); fr(s->vel); fr(s->mass); fr(s->aos); fr(s->scratch);
+  if (s->ev0) (void)hipEventDestroy(s->ev0);
+  if (s->ev1) (void)hipEventDestroy(s->ev1);
+  if (s->stream) (void)hipStreamDestroy(s->stream);
+  s->ev0 = s->ev1 = nullptr;
+  s->stream = nullptr;
+  return rc;
+}
+
+}  // namespace
+
+extern "C" int nbody_mi355x_create(const nbody_mi355x_config* cfg, nbody_mi355x_sim** out) {
+  if (!cfg || !out) { set_error("create: null argument"); return NBODY_MI355X_ERR_INVALID; }
+  *out = nullptr;
+  if (cfg->num_particles <= 0) { set_error("create: num_particles must be > 0"); return NBODY_MI355X_ERR_INVALID; }
+  if (!(cfg->eps2 >= 0.0)) { set_error("create: eps2 must be >= 0"); return NBODY_MI355X_ERR_INVALID; }
+  if (cfg->precision != NBODY_MI355X_FP64 && cfg->precision != NBODY_MI355X_FP32) {
+    set_error("create: unknown precision %d", cfg->precision);
+    return NBODY_MI355X_ERR_INVALID;
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    (void)hipGetLastError();
+    set_error("create: no HIP device visible");
+    return NBODY_MI355X_ERR_NO_DEVICE;
+  }
+  if (cfg->device < 0 || cfg->device >= ndev) {
+    set_error("create: device %d outside [0,%d)", cfg->device, ndev);
+    return NBODY_MI355X_ERR_INVALID;
+  }
+  HIP_TRY(hipSetDevice(cfg->device), NBODY_MI355X_ERR_NO_DEVICE, "hipSetDevice");
+  nbody_mi355x_sim* s = new (std::nothrow) nbody_mi355x_sim();
+  if (!s) { set_error("create: out of host memory"); return NBODY_MI355X_ERR_ALLOC; }
+  s->cfg = *cfg;
+  if (s->cfg.G == 0.0) s->cfg.G = NBODY_MI355X_G_REFERENCE;
+  s->n = cfg->num_particles;
+  s->slots = round_up(s->n, NBODY_MI355X_TILE);
+  const size_t slab = sizeof(double) * 3 * static_cast<size_t>(s->slots);
+  const int64_t eblocks = s->slots / NBODY_MI355X_TILE;
+  bool ok = hipMalloc(&s->pos[0], slab) == hipSuccess && hipMalloc(&s->pos[1], slab) == hipSuccess &&
+            hipMalloc(&s->vel, slab) == hipSuccess &&
+            hipMalloc(&s->mass, sizeof(double) * static_cast<size_t>(s->slots)) == hipSuccess &&
+            hipMalloc(&s->aos, sizeof(double) * 9 * static_cast<size_t>(s->n)) == hipSuccess &&
+            hipMalloc(&s->scratch, sizeof(double) * static_cast<size_t>(2 * eblocks + 2)) == hipSuccess &&
+            hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) == hipSuccess &&
+            hipEventCreate(&s->ev0) == hipSuccess && hipEventCreate(&s->ev1) == hipSuccess;
+  if (!ok) {
+    (void)hipGetLastError();
+    free_all(s);
+    delete s;
+    set_error("create: device allocation failed for N=%lld", (long long)cfg->num_particles);
+    return NBODY_MI355X_ERR_ALLOC;
+  }
+  *out = s;
+  return NBODY_MI355X_OK;
+}
+
+extern "C" int nbody_mi355x_destroy(nbody_mi355x_sim* s) {
+  if (!s) return NBODY_MI355X_OK;
+  (void)hipSetDevice(s->cfg.device);
+  if (s->stream) (void)hipStreamSynchronize(s->stream);
+  int rc = free_all(s);
+  delete s;
+  if (rc != NBODY_MI355X_OK) set_error("destroy: hipFree failed");
+  return rc;
+}
+
+extern "C" int nbody_mi355x_upload(nbody_mi355x_sim* s, const void* particles, const void* mass) {
+  if (!s || !particles || !mass) { set_error("upload: null argument"); return NBODY_MI355X_ERR_INVALID; }
+  HIP_TRY(hipSetDevice(s->cfg.device), NBODY_MI355X_ERR_NO_DEVICE, "hipSetDevice");
+  const size_t n = static_cast<size_t>(s->n);
+  const double* hp = static_cast<const double*>(particles);
+  const double* hm = static_cast<const double*>(mass);
+  if (s->cfg.host_is_float) {
+    s->host_tmp.resize(7 * n);
+    const float* fp = static_cast<const float*>(particles);
+    const float* fm = static_cast<const float*>(mass);
+    for (size_t i = 0; i < 6 * n; i++) s->host_tmp[i] = fp[i];
+    for (size_t i = 0; i < n; i++) s->host_tmp[6 * n + i] = fm[i];
+    hp = s->host_tmp.data();
+    hm = s->host_tmp.data() + 6 * n;
+  }
+  const size_t slab = sizeof(double) * 3 * static_cast<size_t>(s->slots);
+  // padding slots: mass 0 at the origin, in both position buffers, never written again
+  HIP_TRY(hipMemsetAsync(s->pos[0], 0, slab, s->stream), NBODY_MI355X_ERR_H2D, "memset pos0");
+  HIP_TRY(hipMemsetAsync(s->pos[1], 0, slab, s->stream), NBODY_MI355X_ERR_H2D, "memset pos1");
+  HIP_TRY(hipMemsetAsync(s->vel, 0, slab, s->stream), NBODY_MI355X_ERR_H2D, "memset vel");
+  HIP_TRY(hipMemsetAsync(s->mass, 0, sizeof(double) * static_cast<size_t>(s->slots), s->stream),
+          NBODY_MI355X_ERR_H2D, "memset mass");
+  HIP_TRY(hipMemcpyAsync(s->aos, hp, sizeof(double) * 6 * n, hipMemcpyHostToDevice, s->stream),
+          NBODY_MI355X_ERR_H2D, "copy particles");
+  HIP_TRY(hipMemcpyAsync(s->mass, hm, sizeof(double) * n, hipMemcpyHostToDevice, s->stream),
+          NBODY_MI355X_ERR_H2D, "copy masses");
+  s->cur = 0;
+  int rc = nbody_mi355x_pack_f64(s->aos, s->n, s->pos[0], s->vel, s->slots, s->stream);
+  if (rc != NBODY_MI355X_OK) return rc;
+  HIP_TRY(hipStreamSynchronize(s->stream), NBODY_MI355X_ERR_H2D, "upload sync");
+  return NBODY_MI355X_OK;
+}
+
+extern "C" int nbody_mi355x_run(nbody_mi355x_sim* s, int64_t substeps, void* snapshot_out) {
+  if (!s || substeps <= 0) { set_error("run: bad arguments"); return NBODY_MI355X_ERR_INVALID; }
+  HIP_TRY(hipSetDevice(s->cfg.device), NBODY_MI355X_ERR_NO_DEVICE, "hipSetDevice");
+  nbody_mi355x_step_args a;
+  memset(&a, 0, sizeof a);
+  a.mass = s->mass;
+  a.vel = s->vel;
+  a.shard_slots = s->slots;
+  a.num_shards = 1;
+  a.own_shard = 0;
+  a.own_count = s->n;
+  a.j0_begin = 0;
+  a.j0_end = s->n;  // padding slots need not be visited on one GPU
+  a.dt = s->cfg.stepsize;
+  a.G = s->cfg.G;
+  a.eps2 = s->cfg.eps2;
+  a.precision = s->cfg.precision;
+  a.variant = s->cfg.variant;
+  HIP_TRY(hipEventRecord(s->ev0, s->stream), NBODY_MI355X_ERR_LAUNCH, "event record");
+  for (int64_t k = 0; k < substeps; k++) {
+    a.pos_cur = s->pos[s->cur];
+    a.pos_next = s->pos[s->cur ^ 1];
+    a.snapshot = (snapshot_out && k == substeps - 1) ? s->aos : nullptr;
+    int rc = nbody_mi355x_step_f64(&a, s->stream);
+    if (rc != NBODY_MI355X_OK) return rc;
+    s->cur ^= 1;  // ref: pointer swap after every small step, .cu:157-162
+  }
+  HIP_TRY(hipEventRecord(s->ev1, s->stream), NBODY_MI355X_ERR_LAUNCH, "event record");
+  if (snapshot_out) {
+    const size_t n9 = 9 * static_cast<size_t>(s->n);
+    if (s->cfg.host_is_float) {
+      s->host_tmp.resize(n9);
+      HIP_TRY(hipMemcpyAsync(s->host_tmp.data(), s->aos, sizeof(double) * n9, hipMemcpyDeviceToHost, s->stream),
+              NBODY_MI355X_ERR_D2H, "copy snapshot");
+    } else {
+      HIP_TRY(hipMemcpyAsync(snapshot_out, s->aos, sizeof(double) * n9, hipMemcpyDeviceToHost, s->stream),
+              NBODY_MI355X_ERR_D2H, "copy snapshot");
+    }
+  }
+  hipError_t e = hipStreamSynchronize(s->stream);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    set_error("run: %s", hipGetErrorString(e));
+    return NBODY_MI355X_ERR_LAUNCH;
+  }
+  if (snapshot_out && s->cfg.host_is_float) {
+    float* o = static_cast<float*>(snapshot_out);
+    for (size_t i = 0; i < 9 * static_cast<size_t>(s->n); i++) o[i] = static_cast<float>(s->host_tmp[i]);
+  }
+  float ms = 0.f;
+  if (hipEventElapsedTime(&ms, s->ev0, s->ev1) == hipSuccess) s->last_run_seconds = ms * 1e-3;
+  return NBODY_MI355X_OK;
+}
+
+extern "C" int nbody_mi355x_download(nbody_mi355x_sim* s, void* particles) {
+  if (!s || !particles) { set_error("download: null argument"); return NBODY_MI355X_ERR_INVALID; }
+  HIP_TRY(hipSetDevice(s->cfg.device), NBODY_MI355X_ERR_NO_DEVICE, "hipSetDevice");
+  int rc = nbody_mi355x_unpack_f64(s->pos[s->cur], s->vel, s->n, s->slots, s->aos, s->stream);
+  if (rc != NBODY_MI355X_OK) return rc;
+  const size_t n6 = 6 * static_cast<size_t>(s->n);
+  void* dst = particles;
+  if (s->cfg.host_is_float) { s->host_tmp.resize(n6); dst = s->host_tmp.data(); }
+  HIP_TRY(hipMemcpyAsync(dst, s->aos, sizeof(double) * n6, hipMemcpyDeviceToHost, s->stream),
+          NBODY_MI355X_ERR_D2H, "copy state");
+  HIP_TRY(hipStreamSynchronize(s->stream), NBODY_MI355X_ERR_D2H, "download sync");
+  if (s->cfg.host_is_float) {
+    float* o = static_cast<float*>(particles);
+    for (size_t i = 0; i < n6; i++) o[i] = static_cast<float>(s->host_tmp[i]);
+  }
+  return NBODY_MI355X_OK;
+}
+
+extern "C" int nbody_mi355x_energy(nbody_mi355x_sim* s, double* ke, double* pe) {
+  if (!s || !ke || !pe) { set_error("energy: null argument"); return NBODY_MI355X_ERR_INVALID; }
+  HIP_TRY(hipSetDevice(s->cfg.device), NBODY_MI355X_ERR_NO_DEVICE, "hipSetDevice");
+  const int64_t eblocks = s->slots / NBODY_MI355X_TILE;
+  double* result = s->scratch + 2 * eblocks;
+  int rc = nbody_mi355x_energy_f64(s->pos[s->cur], s->mass, s->vel, s->slots, 1, 0, s->n, s->cfg.G,
+                                   s->scratch, result, s->stream);
+  if (rc != NBODY_MI355X_OK) return rc;
+  double h[2] = {0, 0};
+  HIP_TRY(hipMemcpyAsync(h, result, sizeof h, hipMemcpyDeviceToHost, s->stream), NBODY_MI355X_ERR_D2H,
+          "copy energy");
+  HIP_TRY(hipStreamSynchronize(s->stream), NBODY_MI355X_ERR_D2H, "energy sync");
+  *ke = h[0];
+  *pe = h[1];
+  return NBODY_MI355X_OK;
+}
+
+extern "C" int nbody_mi355x_last_run_seconds(nbody_mi355x_sim* s, double* seconds) {
+  if (!s || !seconds) { set_error("last_run_seconds: null argument"); return NBODY_MI355X_ERR_INVALID; }
+  *seconds = s->last_run_seconds;
+  return NBODY_MI355X_OK;
+}

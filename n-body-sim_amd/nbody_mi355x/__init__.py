@@ -1,0 +1,198 @@
+"""ctypes binding of libnbody_mi355x.so (C ABI: include/nbody_mi355x.h).
+
+This package is plumbing for tests and bench.py: it loads the in-tree shared
+library and mirrors its C structs.  There is NO fallback: if the library is not
+built, or a call fails, an exception is raised -- nothing here computes forces
+on the CPU.
+
+If torch is going to be used in the same process, import torch BEFORE this
+module: both link libamdhip64.so.7 and must share one HIP runtime (the first
+one loaded wins).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+import numpy as np
+
+PKG_DIR = Path(__file__).resolve().parent
+ROOT = PKG_DIR.parent  # n-body-sim_amd/
+LIB_PATH = ROOT / "lib" / "libnbody_mi355x.so"
+
+TILE = 256
+G_REFERENCE = 6.7430e-11  # reference: particle_simulation.h:713
+FP64, FP32 = 0, 1
+
+OK = 0
+ERR_INVALID, ERR_ALLOC, ERR_H2D, ERR_D2H, ERR_FREE, ERR_LAUNCH, ERR_NO_DEVICE = range(-1, -8, -1)
+
+
+class NBodyError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"nbody_mi355x error {code}: {msg}")
+        self.code = code
+
+
+class StepArgs(C.Structure):
+    """nbody_mi355x_step_args"""
+    _fields_ = [
+        ("pos_cur", C.c_void_p), ("pos_next", C.c_void_p), ("mass", C.c_void_p),
+        ("vel", C.c_void_p), ("acc_in", C.c_void_p), ("acc_out", C.c_void_p),
+        ("snapshot", C.c_void_p),
+        ("shard_slots", C.c_int64), ("num_shards", C.c_int32), ("own_shard", C.c_int32),
+        ("own_count", C.c_int64),
+        ("j0_begin", C.c_int64), ("j0_end", C.c_int64), ("j1_begin", C.c_int64), ("j1_end", C.c_int64),
+        ("dt", C.c_double), ("G", C.c_double), ("eps2", C.c_double),
+        ("precision", C.c_int32), ("variant", C.c_int32),
+    ]
+
+
+class Config(C.Structure):
+    """nbody_mi355x_config"""
+    _fields_ = [
+        ("num_particles", C.c_int64), ("stepsize", C.c_double), ("G", C.c_double),
+        ("eps2", C.c_double), ("precision", C.c_int32), ("device", C.c_int32),
+        ("host_is_float", C.c_int32), ("variant", C.c_int32),
+    ]
+
+
+# every symbol include/nbody_mi355x.h declares: (restype, argtypes)
+_P = C.c_void_p
+SYMBOLS = {
+    "nbody_mi355x_last_error": (C.c_char_p, []),
+    "nbody_mi355x_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "nbody_mi355x_step_f64": (C.c_int, [C.POINTER(StepArgs), _P]),
+    "nbody_mi355x_pack_f64": (C.c_int, [_P, C.c_int64, _P, _P, C.c_int64, _P]),
+    "nbody_mi355x_unpack_f64": (C.c_int, [_P, _P, C.c_int64, C.c_int64, _P, _P]),
+    "nbody_mi355x_energy_f64": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int64,
+                                          C.c_double, _P, _P, _P]),
+    "nbody_mi355x_create": (C.c_int, [C.POINTER(Config), C.POINTER(_P)]),
+    "nbody_mi355x_destroy": (C.c_int, [_P]),
+    "nbody_mi355x_upload": (C.c_int, [_P, _P, _P]),
+    "nbody_mi355x_run": (C.c_int, [_P, C.c_int64, _P]),
+    "nbody_mi355x_download": (C.c_int, [_P, _P]),
+    "nbody_mi355x_energy": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "nbody_mi355x_last_run_seconds": (C.c_int, [_P, C.POINTER(C.c_double)]),
+    "nbody_mi355x_ic_plummer": (C.c_int, [C.c_int64, C.c_uint64, C.c_double, _P, _P]),
+    "nbody_mi355x_ic_uniform_cube": (C.c_int, [C.c_int64, C.c_uint64, C.c_double, _P, _P]),
+}
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load the shared library (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise FileNotFoundError(
+                f"{LIB_PATH} is missing: build it with `make -C {ROOT}` (or __graft_entry__.build()); "
+                "there is no CPU fallback")
+        L = C.CDLL(str(LIB_PATH), mode=getattr(os, "RTLD_NOW", 2))
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)  # AttributeError if the export is missing
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def last_error() -> str:
+    return (lib().nbody_mi355x_last_error() or b"").decode()
+
+
+def check(rc: int) -> None:
+    if rc != OK:
+        raise NBodyError(rc, last_error())
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    rc = lib().nbody_mi355x_device_count(C.byref(n))
+    return n.value if rc == OK else 0
+
+
+def round_up(v: int, m: int = TILE) -> int:
+    return (v + m - 1) // m * m
+
+
+def _np(a, dtype=np.float64):
+    a = np.ascontiguousarray(a, dtype=dtype)
+    return a, a.ctypes.data_as(C.c_void_p)
+
+
+# ---------------------------------------------------------------- initial conditions
+def ic_plummer(n: int, seed: int = 42, G: float = G_REFERENCE):
+    """Particle<double>[n] as an (n,6) array {r,v} and masses (n,)."""
+    p = np.empty((n, 6), dtype=np.float64)
+    m = np.empty(n, dtype=np.float64)
+    check(lib().nbody_mi355x_ic_plummer(n, seed, G, p.ctypes.data_as(_P), m.ctypes.data_as(_P)))
+    return p, m
+
+
+def ic_uniform_cube(n: int, seed: int = 7, G: float = G_REFERENCE):
+    p = np.empty((n, 6), dtype=np.float64)
+    m = np.empty(n, dtype=np.float64)
+    check(lib().nbody_mi355x_ic_uniform_cube(n, seed, G, p.ctypes.data_as(_P), m.ctypes.data_as(_P)))
+    return p, m
+
+
+# ---------------------------------------------------------------- handle API
+class Simulation:
+    """The handle API, as ParticleSimulation::SimulateMI355X() uses it:
+    create -> upload -> run (one call per big step) -> destroy."""
+
+    def __init__(self, num_particles: int, stepsize: float, *, G: float = G_REFERENCE,
+                 eps2: float = 0.0, precision: int = FP64, device: int = 0,
+                 host_is_float: bool = False, variant: int = 0):
+        self.n = int(num_particles)
+        self.host_dtype = np.float32 if host_is_float else np.float64
+        cfg = Config(self.n, stepsize, G, eps2, precision, device, int(host_is_float), variant)
+        h = C.c_void_p()
+        check(lib().nbody_mi355x_create(C.byref(cfg), C.byref(h)))
+        self._h = h
+
+    def upload(self, particles, mass) -> None:
+        p, pp = _np(np.asarray(particles).reshape(self.n, 6), self.host_dtype)
+        m, mp = _np(np.asarray(mass).reshape(self.n), self.host_dtype)
+        check(lib().nbody_mi355x_upload(self._h, pp, mp))
+
+    def run(self, substeps: int, snapshot: bool = True):
+        """One big step.  Returns DeviceOutputParticle[n] as (n,9) {r,v,a*G} or None."""
+        out = np.empty((self.n, 9), dtype=self.host_dtype) if snapshot else None
+        check(lib().nbody_mi355x_run(self._h, substeps, out.ctypes.data_as(_P) if snapshot else None))
+        return out
+
+    def download(self):
+        p = np.empty((self.n, 6), dtype=self.host_dtype)
+        check(lib().nbody_mi355x_download(self._h, p.ctypes.data_as(_P)))
+        return p
+
+    def energy(self):
+        ke, pe = C.c_double(), C.c_double()
+        check(lib().nbody_mi355x_energy(self._h, C.byref(ke), C.byref(pe)))
+        return ke.value, pe.value
+
+    def last_run_seconds(self) -> float:
+        s = C.c_double()
+        check(lib().nbody_mi355x_last_run_seconds(self._h, C.byref(s)))
+        return s.value
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            h, self._h = self._h, None
+            check(lib().nbody_mi355x_destroy(h))
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
