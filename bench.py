@@ -1,0 +1,170 @@
+#!/usr/bin/env python3
+"""bench.py -- Ginteractions/s of the all-pairs hot path (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--n BODIES]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one small step (one pass of the O(N^2) force accumulation + fused Euler
+update) over the whole synthetic system.  Workload: Plummer sphere, N = 1,048,576,
+fp64, seed 42 (BASELINE.json configs[3]; the configuration the metric is quoted on);
+with --gpus N the SAME system is sharded over N ranks (strong scaling), positions
+all-gathered with RCCL every step.  Inputs are resident in HBM before the timed
+region.  One JSON line on stdout (rank 0).
+
+Extra objects in the line:
+  roofline      FP64 vector-ALU roofline of the step kernel: 20 FLOP per interaction
+                 / average launch duration measured with HIP
+                events on the launch stream, against the 78.6 TFLOP/s vector peak.
+  cpu_baseline  the reference's own SimulateAVX2() (compiled from /root/reference in the
+                build container into oracle/_ref/libnbody_ref.so; kind "reference"), or
+                the oracle's restatement of it (kind "port") when that file is absent,
+                on this host's cores, on a bounded sample.  N=1 only, rank 0 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+REPO = Path(__file__).resolve().parent
+sys.path.insert(0, str(REPO / "n-body-sim_amd"))
+sys.path.insert(0, str(REPO / "tests"))
+
+FLOP_PER_INTERACTION = 20.0      # BASELINE.md section 3 / SURVEY 8d convention
+FP64_VECTOR_PEAK_TFLOPS = 78.6   # 256 CU x 64 FMA lanes x 2 x 2.4 GHz (MI355X_MICROARCH.md)
+
+
+def cpu_baseline(budget_s=15.0):
+    """Time the reference's multithreaded AVX2 path on this host (bounded sample)."""
+    import numpy as np  # noqa: F401
+    import nbody_mi355x as nb
+    import oracle_lib as ol
+    threads = max(1, min(16, os.cpu_count() or 1))   # the box's CPU share for one GPU is 16
+    n = 32768
+    p, m = nb.ic_plummer(n, 42)
+    kind = "reference" if ol.have_ref() else "port"
+
+    def run(sub):
+        if kind == "reference":
+            _, sec = ol.ref_simulate(p, m, 1, sub, 1e-3, threads=threads, mode="avx2")
+            return sec
+        t0 = time.perf_counter()
+        ol.simulate(p, m, 1, sub, 1e-3, threads=threads, kind="avx2")
+        return time.perf_counter() - t0
+
+    t_probe = run(2) / 2
+    sub = int(max(3, min(400, budget_s / max(t_probe, 1e-6))))
+    sec = run(sub)
+    return {
+        "value": round(n * n * sub / sec / 1e9, 3), "unit": "Ginteractions/s", "cores": threads,
+        "kind": kind,
+        "sample": f"SimulateAVX2(), Plummer N={n} fp64 seed 42, {sub} small steps, {threads} threads, {sec:.1f} s",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n", type=int, default=1048576)
+    ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--precision", choices=["fp64", "fp32"], default="fp64")
+    ap.add_argument("--no-overlap", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import nbody_mi355x as nb
+    from nbody_mi355x.sharded import HipBackend, ShardedNBody
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit(f"--gpus {args.gpus} needs a launcher: python -m torch.distributed.run "
+                     f"--nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 bench.py --gpus {args.gpus} ...")
+        sys.exit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU (there is no CPU fallback for the product path)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    n, K, W = args.n, args.steps, args.warmup
+    prec = nb.FP64 if args.precision == "fp64" else nb.FP32
+    p, m = nb.ic_plummer(n, 42)                       # same ICs on every rank
+    sim = ShardedNBody(p, m, 1e-3, rank=rank, world=world, device=device,
+                       backend=HipBackend(precision=prec, variant=args.variant),
+                       overlap=not args.no_overlap)
+    del p, m
+
+    def barrier():
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(device)
+
+    for _ in range(W):
+        sim.step()
+    barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()                                       # torch's current stream == the launch stream
+    for _ in range(K):
+        sim.step()
+    ev1.record()
+    barrier()
+    wall = time.perf_counter() - t0
+    dev_s = ev0.elapsed_time(ev1) * 1e-3
+    if world > 1:
+        t = torch.tensor([wall, dev_s], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall, dev_s = float(t[0]), float(t[1])
+
+    if rank == 0:
+        inter_per_step = float(n) * float(n)
+        value = inter_per_step * K / wall / 1e9
+        # dominant kernel: the step kernel; one launch per step and rank at N=1 (two at N>1,
+        # own-slab half + remote half, timed together), each rank doing n * n/world pairs
+        ach = FLOP_PER_INTERACTION * (inter_per_step / world) * K / dev_s / 1e12
+        peak = FP64_VECTOR_PEAK_TFLOPS * (2.0 if prec == nb.FP32 else 1.0)
+        traffic = None
+        tf = REPO / "profiles" / "traffic.json"
+        if tf.exists() and world == 1:
+            try:
+                traffic = json.loads(tf.read_text()).get(f"n{n}_{args.precision}")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "Ginteractions/s at N=1M fp64, 1/2/4/8 MI355X; % of FP64 vector peak",
+            "value": round(value, 2), "unit": "Ginteractions/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": round(wall / K * 1e3, 3), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f64" if prec == nb.FP64 else "f32", "data": "synthetic",
+            "config": {"workload": f"plummer_sphere_n{n}_{args.precision}_seed42_dt1e-3",
+                       "bodies": n, "interactions_per_step": inter_per_step,
+                       "parallelism": f"i-shard x{world}, RCCL all-gather of positions per step"
+                       + ("" if args.no_overlap or world == 1 else ", overlapped with the own-slab half"),
+                       "kernel_variant": args.variant},
+            "roofline": {"bound": "valu_fp64" if prec == nb.FP64 else "valu_fp32", "achieved": round(ach, 3),
+                         "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
+                         "kernel": "step_kernel", "avg_launch_ms": round(dev_s / K * 1e3, 3),
+                         "flop_per_interaction": FLOP_PER_INTERACTION},
+            "pct_of_fp64_vector_peak": round(100 * ach / FP64_VECTOR_PEAK_TFLOPS, 2),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -90,6 +90,12 @@ def lib() -> C.CDLL:
             raise FileNotFoundError(
                 f"{LIB_PATH} is missing: build it with `make -C {ROOT}` (or __graft_entry__.build()); "
                 "there is no CPU fallback")
+        try:
+            # torch bundles its own libamdhip64.so.7; load it first so that this process
+            # has ONE HIP runtime whichever of the two the caller touches first
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(str(LIB_PATH), mode=getattr(os, "RTLD_NOW", 2))
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(L, name)  # AttributeError if the export is missing

@@ -1,0 +1,149 @@
+"""One-rank-per-GPU driver of the hot path: i-bodies sharded, positions all-gathered.
+
+The reference parallelises MakeSmallStep over contiguous i ranges, remainder to
+the low ids (particle_simulation.h:98-110), with all positions in shared
+memory.  Across GPUs the same split is kept -- rank r owns the bodies thread r
+would own -- and the shared memory becomes one exchange per small step: every
+rank all-gathers the positions it has just updated (velocities stay private;
+no reduction is needed because each rank produces complete a_i).
+
+Layout: the slab layout of include/nbody_mi355x.h, [world][3][S] with
+S = max shard size rounded up to the 256-body tile, so that the exchange is
+ONE in-place all_gather_into_tensor of 3*S doubles per rank.
+
+Overlap: while the collective for small step k is in flight (RCCL runs it on
+its own stream), the rank already accumulates the forces from its OWN slab,
+which it holds (step_args.acc_out, first half of a split step); after
+work.wait() a second launch adds the remote slabs and integrates.
+
+torch is plumbing here (device memory, streams, torch.distributed); the
+arithmetic is in libnbody_mi355x.so.  `backend` exists so that the CPU test of
+this host logic (gloo, world_size 2) can substitute a checker for the kernel;
+the default is the HIP library and there is no fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import FP64, G_REFERENCE, TILE, StepArgs, check, lib, round_up
+
+
+def shard_counts(n: int, world: int):
+    """particle_simulation.h:98-110: n // world each, remainder to the low ranks."""
+    base, rem = divmod(n, world)
+    counts = [base + (1 if r < rem else 0) for r in range(world)]
+    begins = [base * r + min(r, rem) for r in range(world)]
+    return counts, begins
+
+
+class HipBackend:
+    """Calls nbody_mi355x_step_f64 on torch-owned device memory."""
+
+    def __init__(self, precision=FP64, variant=0):
+        self.precision, self.variant = precision, variant
+        self._lib = lib()
+
+    def step(self, *, pos_cur, pos_next, mass, vel, acc_in, acc_out, snapshot, S, world, rank, count,
+             ranges, dt, G, eps2):
+        a = StepArgs()
+        a.pos_cur, a.pos_next, a.mass, a.vel = pos_cur.data_ptr(), pos_next.data_ptr(), mass.data_ptr(), vel.data_ptr()
+        a.acc_in = acc_in.data_ptr() if acc_in is not None else None
+        a.acc_out = acc_out.data_ptr() if acc_out is not None else None
+        a.snapshot = snapshot.data_ptr() if snapshot is not None else None
+        a.shard_slots, a.num_shards, a.own_shard, a.own_count = S, world, rank, count
+        (a.j0_begin, a.j0_end), (a.j1_begin, a.j1_end) = ranges
+        a.dt, a.G, a.eps2 = dt, G, eps2
+        a.precision, a.variant = self.precision, self.variant
+        stream = torch.cuda.current_stream(pos_cur.device).cuda_stream
+        check(self._lib.nbody_mi355x_step_f64(C.byref(a), C.c_void_p(stream)))
+
+
+class ShardedNBody:
+    def __init__(self, particles, mass, dt, *, rank=0, world=1, device="cuda", G=G_REFERENCE, eps2=0.0,
+                 backend=None, overlap=True, group=None):
+        particles = np.ascontiguousarray(particles, dtype=np.float64).reshape(-1, 6)
+        mass = np.ascontiguousarray(mass, dtype=np.float64)
+        self.n, self.rank, self.world = particles.shape[0], rank, world
+        self.dt, self.G, self.eps2 = float(dt), float(G), float(eps2)
+        self.overlap, self.group = overlap, group
+        self.device = torch.device(device)
+        self.backend = backend if backend is not None else HipBackend()
+        self.counts, self.begins = shard_counts(self.n, world)
+        self.count = self.counts[rank]
+        self.S = S = round_up(max(self.counts), TILE)
+
+        # host image of the slab layout; padding slots: mass 0 at the origin
+        pos = np.zeros((world, 3, S))
+        m = np.zeros((world, S))
+        for r in range(world):
+            b, c = self.begins[r], self.counts[r]
+            pos[r, :, :c] = particles[b:b + c, :3].T
+            m[r, :c] = mass[b:b + c]
+        vel = np.zeros((3, S))
+        b, c = self.begins[rank], self.count
+        vel[:, :c] = particles[b:b + c, 3:].T
+
+        dev = self.device
+        self.pos = [torch.from_numpy(pos).to(dev), torch.from_numpy(pos.copy()).to(dev)]
+        self.mass = torch.from_numpy(m).to(dev)
+        self.vel = torch.from_numpy(vel).to(dev)
+        self.acc = torch.zeros((3, S), dtype=torch.float64, device=dev)
+        self.snap = torch.zeros((max(self.count, 1), 9), dtype=torch.float64, device=dev)
+        self.cur = 0
+        self._fresh = True  # every slab of pos[cur] is current (true right after upload)
+
+    # ------------------------------------------------------------------ one small step
+    def step(self, snapshot=False):
+        cur, nxt = self.pos[self.cur], self.pos[self.cur ^ 1]
+        S, P, r = self.S, self.world, self.rank
+        common = dict(pos_cur=cur, pos_next=nxt, mass=self.mass, vel=self.vel, S=S, world=P, rank=r,
+                      count=self.count, dt=self.dt, G=self.G, eps2=self.eps2)
+        snap = self.snap if snapshot else None
+        if P == 1:
+            self.backend.step(acc_in=None, acc_out=None, snapshot=snap, ranges=((0, self.n), (0, 0)), **common)
+        elif not self.overlap or self._fresh:
+            if not self._fresh:
+                self._all_gather(cur, async_op=False)
+            self.backend.step(acc_in=None, acc_out=None, snapshot=snap, ranges=((0, P * S), (0, 0)), **common)
+        else:
+            work = self._all_gather(cur, async_op=True)           # remote slabs, in flight
+            self.backend.step(acc_in=None, acc_out=self.acc, snapshot=None,
+                              ranges=((r * S, (r + 1) * S), (0, 0)), **common)   # own slab meanwhile
+            work.wait()                                           # stream-ordered, not a host block
+            self.backend.step(acc_in=self.acc, acc_out=None, snapshot=snap,
+                              ranges=((0, r * S), ((r + 1) * S, P * S)), **common)
+        self.cur ^= 1
+        self._fresh = False
+
+    def _all_gather(self, buf, async_op):
+        import torch.distributed as dist
+        flat = buf.view(-1)
+        own = flat[self.rank * 3 * self.S:(self.rank + 1) * 3 * self.S]
+        return dist.all_gather_into_tensor(flat, own, group=self.group, async_op=async_op)
+
+    def sync_positions(self):
+        """Make every slab of the current buffer current (needed before reading remote slabs)."""
+        if self.world > 1 and not self._fresh:
+            self._all_gather(self.pos[self.cur], async_op=False)
+            self._fresh = True
+
+    # ------------------------------------------------------------------ results
+    def own_state(self):
+        """Particle rows (count, 6) of this rank's bodies."""
+        c = self.count
+        pos = self.pos[self.cur][self.rank, :, :c].T.cpu().numpy()
+        vel = self.vel[:, :c].T.cpu().numpy()
+        return np.concatenate([pos, vel], axis=1)
+
+    def own_snapshot(self):
+        """DeviceOutputParticle rows (count, 9) written by the last step(snapshot=True)."""
+        return self.snap[:self.count].cpu().numpy()
+
+    def all_positions(self):
+        """(n, 3) positions of every body (collective)."""
+        self.sync_positions()
+        p = self.pos[self.cur].cpu().numpy()
+        return np.concatenate([p[r, :, :self.counts[r]].T for r in range(self.world)], axis=0)

@@ -1,0 +1,86 @@
+"""CPU-only checks of the boundary and the host logic: the C-ABI library loads and exports
+every symbol include/nbody_mi355x.h declares (no compute calls without a GPU), argument
+validation fails loudly, the IC generators are deterministic, and the shard partition
+follows the reference's thread partition."""
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import nbody_mi355x as nb
+from nbody_mi355x.sharded import shard_counts
+
+REPO = Path(__file__).resolve().parent.parent
+
+
+def test_header_symbols_all_exported_and_bound():
+    header = (REPO / "include" / "nbody_mi355x.h").read_text()
+    declared = set(re.findall(r"\b(nbody_mi355x_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations found"
+    L = nb.lib()
+    for name in declared:
+        assert hasattr(L, name), f"{name} declared in the header but not exported"
+    assert declared == set(nb.SYMBOLS), "python binding and header disagree"
+
+
+def test_struct_sizes_match_header_layout():
+    import ctypes as C
+    # 7 pointers + int64 + 2 int32 + 5 int64 + 3 double + 2 int32
+    assert C.sizeof(nb.StepArgs) == 7 * 8 + 8 + 8 + 5 * 8 + 3 * 8 + 8
+    assert C.sizeof(nb.Config) == 8 + 3 * 8 + 4 * 4
+
+
+def test_invalid_arguments_fail_loudly_without_gpu():
+    import ctypes as C
+    L = nb.lib()
+    a = nb.StepArgs()
+    assert L.nbody_mi355x_step_f64(C.byref(a), None) == nb.ERR_INVALID
+    assert "null" in nb.last_error()
+    a.pos_cur, a.mass = 8, 8  # never dereferenced: validation rejects before any launch
+    a.shard_slots = 100  # not a multiple of the tile
+    assert L.nbody_mi355x_step_f64(C.byref(a), None) == nb.ERR_INVALID
+    assert "multiple of 256" in nb.last_error()
+    cfg = nb.Config(0, 0.1, 0, 0, 0, 0, 0, 0)
+    h = C.c_void_p()
+    assert L.nbody_mi355x_create(C.byref(cfg), C.byref(h)) == nb.ERR_INVALID
+    with pytest.raises(nb.NBodyError):
+        nb.ic_plummer(0)
+
+
+def test_product_package_never_touches_the_oracle():
+    for f in (REPO / "n-body-sim_amd").rglob("*"):
+        if f.suffix in {".py", ".hip", ".cpp", ".h", ".hpp"} or f.name == "Makefile":
+            assert "oracle" not in f.read_text().replace("test_oracle", ""), f"{f} mentions the oracle"
+
+
+def test_ic_plummer_deterministic_and_sane():
+    p, m = nb.ic_plummer(4096, 42)
+    p2, m2 = nb.ic_plummer(4096, 42)
+    assert np.array_equal(p, p2) and np.array_equal(m, m2)
+    p3, _ = nb.ic_plummer(4096, 43)
+    assert not np.array_equal(p, p3)
+    assert np.allclose(m * nb.G_REFERENCE * 4096, 1.0)
+    assert np.abs(p[:, :3].mean(0)).max() < 1e-12 and np.abs(p[:, 3:].mean(0)).max() < 1e-12
+    r = np.linalg.norm(p[:, :3], axis=1)
+    assert r.max() < 10.5
+    assert 1.2 < np.median(r) < 1.4  # Plummer half-mass radius = 1.305 a (slightly less when truncated)
+    v2 = (p[:, 3:] ** 2).sum(1).mean()
+    assert 0.2 < v2 < 0.4  # <v^2> = 3 pi / 32 = 0.295 in G M = a = 1
+
+
+def test_ic_uniform_cube():
+    p, m = nb.ic_uniform_cube(1000, 7)
+    assert np.all(np.abs(p[:, :3]) <= 1) and np.all(p[:, 3:] == 0)
+    assert np.allclose(m.sum() * nb.G_REFERENCE, 1.0)
+
+
+@pytest.mark.parametrize("n,world", [(5, 3), (500, 8), (1048576, 8), (7, 8), (4194304, 8)])
+def test_shard_partition_matches_reference_threads(n, world):
+    counts, begins = shard_counts(n, world)
+    # particle_simulation.h:98-110, e.g. 5 particles, 3 threads -> 2,2,1
+    assert sum(counts) == n and max(counts) - min(counts) <= 1
+    assert counts == sorted(counts, reverse=True)
+    assert begins == [sum(counts[:r]) for r in range(world)]
+    if (n, world) == (5, 3):
+        assert counts == [2, 2, 1]

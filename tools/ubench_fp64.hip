@@ -1,0 +1,133 @@
+// ubench_fp64.hip -- measures, on the GPU it runs on, the issue cost of the FP64 vector
+// instructions the step kernel is made of, and the accuracy of v_rsq_f64 and of the
+// kernel's r^-3 formula.  Feeds the slot budget in DESIGN.md.  Build: make -C tools.
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+constexpr int CH = 8;       // independent chains per lane
+constexpr int ITERS = 2048;  // loop trips; CH ops of the measured kind per trip
+
+enum Op { FMA64, MUL64, ADD64, RSQ64, RCP64, SQRT64HW, CVT_PAIR, RSQ32, FMA32, PKFMA32, MIX_PAIR, NOPS };
+static const char* kNames[NOPS] = {"v_fma_f64", "v_mul_f64", "v_add_f64", "v_rsq_f64", "v_rcp_f64", "v_sqrt_f64",
+                                   "v_cvt_f32_f64+v_cvt_f64_f32 (2 ops)", "v_rsq_f32", "v_fma_f32", "v_pk_fma_f32",
+                                   "pair_f64 body (16 fp64 + rsq)"};
+static const int kOpsPerChainStep[NOPS] = {1, 1, 1, 1, 1, 1, 2, 1, 1, 1, 17};
+
+template <int OP>
+__global__ __launch_bounds__(256) void k(double* out, double a, double b) {
+  double x[CH];
+  float f[CH];
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  f2 p[CH];
+#pragma unroll
+  for (int c = 0; c < CH; c++) { x[c] = 1.0 + 1e-3 * (threadIdx.x + c); f[c] = (float)x[c]; p[c] = f2{f[c], f[c] + 1.f}; }
+  double ax = 0, ay = 0, az = 0;
+  for (int it = 0; it < ITERS; it++) {
+#pragma unroll
+    for (int c = 0; c < CH; c++) {
+      if (OP == FMA64) x[c] = __builtin_fma(x[c], a, b);
+      if (OP == MUL64) x[c] = x[c] * a;
+      if (OP == ADD64) x[c] = x[c] + a;
+      if (OP == RSQ64) x[c] = __builtin_amdgcn_rsq(x[c]);
+      if (OP == RCP64) x[c] = __builtin_amdgcn_rcp(x[c]);
+      if (OP == SQRT64HW) x[c] = __builtin_amdgcn_sqrt(x[c]);
+      if (OP == CVT_PAIR) { float t = (float)x[c]; asm volatile("" : "+v"(t)); x[c] = (double)t; }
+      if (OP == RSQ32) f[c] = __builtin_amdgcn_rsqf(f[c]);
+      if (OP == FMA32) f[c] = __builtin_fmaf(f[c], (float)a, (float)b);
+      if (OP == PKFMA32) p[c] = __builtin_elementwise_fma(p[c], f2{(float)a, (float)a}, f2{(float)b, (float)b});
+      if (OP == MIX_PAIR) {
+        const double dx = x[c] - a, dy = x[c] - b, dz = a - x[c];
+        const double r2 = __builtin_fma(dz, dz, __builtin_fma(dy, dy, __builtin_fma(dx, dx, 0x1p-600)));
+        const double y0 = __builtin_amdgcn_rsq(r2);
+        const double u = y0 * y0;
+        const double e = __builtin_fma(-r2, u, 1.0);
+        const double q = b * y0;
+        const double w = q * u;
+        const double pp = __builtin_fma(e, 1.875 + a, 1.5 + a);
+        const double we = w * e;
+        const double s = __builtin_fma(we, pp, w);
+        ax = __builtin_fma(s, dx, ax); ay = __builtin_fma(s, dy, ay); az = __builtin_fma(s, dz, az);
+      }
+    }
+  }
+  double s = ax + ay + az;
+#pragma unroll
+  for (int c = 0; c < CH; c++) s += x[c] + f[c] + p[c].x + p[c].y;
+  if (s == 123.456) out[0] = s;  // keep everything live, never true
+}
+
+template <int OP>
+void run(double* d_out, int waves_per_simd, int cus) {
+  const int blocks = cus * waves_per_simd;  // 256 threads = 4 waves = one per SIMD of a CU
+  hipEvent_t e0, e1;
+  CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+  hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(256), 0, 0, d_out, 1.0000001, 1e-9);
+  CHECK(hipDeviceSynchronize());
+  float best = 1e30f;
+  for (int r = 0; r < 3; r++) {
+    CHECK(hipEventRecord(e0));
+    hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(256), 0, 0, d_out, 1.0000001, 1e-9);
+    CHECK(hipEventRecord(e1));
+    CHECK(hipEventSynchronize(e1));
+    float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+    if (ms < best) best = ms;
+  }
+  const double wave_instr_per_simd = (double)ITERS * CH * kOpsPerChainStep[OP] * waves_per_simd;
+  const double ns_per_instr = best * 1e6 / wave_instr_per_simd;
+  printf("%-40s waves/SIMD=%d  %8.3f ms  %7.3f ns per wave-instr per SIMD  (= %5.2f cycles @2.4GHz)\n",
+         kNames[OP], waves_per_simd, best, ns_per_instr, ns_per_instr * 2.4);
+}
+
+// accuracy: seed error of v_rsq_f64 and error of the corrected m*r^-3 against IEEE div/sqrt
+__global__ void acc_kernel(const double* r2s, int n, double* seed_err, double* s_err1, double* s_err2) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double r2 = r2s[i];
+  const double y0 = __builtin_amdgcn_rsq(r2);
+  const double exact_y = 1.0 / sqrt(r2);
+  seed_err[i] = fabs(y0 / exact_y - 1.0);
+  const double exact = 1.0 / (r2 * sqrt(r2));
+  const double u = y0 * y0, e = __builtin_fma(-r2, u, 1.0), w = y0 * u;
+  const double s2 = __builtin_fma(w * e, __builtin_fma(e, 1.875, 1.5), w);
+  const double s1 = __builtin_fma(w * e, 1.5, w);
+  s_err2[i] = fabs(s2 / exact - 1.0);
+  s_err1[i] = fabs(s1 / exact - 1.0);
+}
+
+int main() {
+  hipDeviceProp_t prop;
+  CHECK(hipGetDeviceProperties(&prop, 0));
+  printf("device: %s, %d CUs, clockRate %d kHz\n", prop.name, prop.multiProcessorCount, prop.clockRate);
+  double* d_out; CHECK(hipMalloc(&d_out, 64));
+  const int cus = prop.multiProcessorCount;
+  for (int w : {1, 2, 4}) {
+    run<FMA64>(d_out, w, cus); run<MUL64>(d_out, w, cus); run<ADD64>(d_out, w, cus);
+    run<RSQ64>(d_out, w, cus); run<RCP64>(d_out, w, cus); run<SQRT64HW>(d_out, w, cus);
+    run<CVT_PAIR>(d_out, w, cus); run<RSQ32>(d_out, w, cus); run<FMA32>(d_out, w, cus);
+    run<PKFMA32>(d_out, w, cus); run<MIX_PAIR>(d_out, w, cus);
+    printf("\n");
+  }
+  const int n = 1 << 22;
+  std::vector<double> h(n);
+  srand(1);
+  for (int i = 0; i < n; i++) h[i] = pow(10.0, -12.0 + 24.0 * (rand() / (double)RAND_MAX)) * (1.0 + rand() / (double)RAND_MAX);
+  double *d_r2, *d_e0, *d_e1, *d_e2;
+  CHECK(hipMalloc(&d_r2, n * 8)); CHECK(hipMalloc(&d_e0, n * 8)); CHECK(hipMalloc(&d_e1, n * 8)); CHECK(hipMalloc(&d_e2, n * 8));
+  CHECK(hipMemcpy(d_r2, h.data(), n * 8, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(acc_kernel, dim3(n / 256), dim3(256), 0, 0, d_r2, n, d_e0, d_e1, d_e2);
+  std::vector<double> e0(n), e1(n), e2(n);
+  CHECK(hipMemcpy(e0.data(), d_e0, n * 8, hipMemcpyDeviceToHost));
+  CHECK(hipMemcpy(e1.data(), d_e1, n * 8, hipMemcpyDeviceToHost));
+  CHECK(hipMemcpy(e2.data(), d_e2, n * 8, hipMemcpyDeviceToHost));
+  double m0 = 0, m1 = 0, m2 = 0;
+  for (int i = 0; i < n; i++) { m0 = fmax(m0, e0[i]); m1 = fmax(m1, e1[i]); m2 = fmax(m2, e2[i]); }
+  printf("v_rsq_f64 seed: max rel err %.3e (2^%.1f) over %d values in [1e-12,2e12]\n", m0, log2(m0), n);
+  printf("r^-3 with 1st-order correction: max rel err %.3e (%.1f ulp)\n", m1, m1 / 0x1p-53);
+  printf("r^-3 with 2nd-order correction (kernel): max rel err %.3e (%.1f ulp)\n", m2, m2 / 0x1p-53);
+  return 0;
+}
