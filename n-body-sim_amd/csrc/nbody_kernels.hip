@@ -72,19 +72,21 @@ __device__ __forceinline__ void pair_f64(double xi, double yi, double zi, double
   az = __builtin_fma(s, dz, az);
 }
 
-// Mixed variant: separations and r^2 in double (so that close pairs of bodies
-// far from the origin do not cancel catastrophically), r^-3 and the running
-// sums in float.  v_rsq_f32 is accurate to ~1 ulp, no correction step.
+// Mixed variant: separations in double (so that close pairs of bodies far from the
+// origin do not cancel catastrophically), r^2, r^-3 and the running sums in float.
+// v_rsq_f32 is accurate to ~1 ulp, no correction step.  The 2^-600 trick of the double
+// path does not fit float's exponent range (m * y0^3 would overflow for r^2 -> 0), so the
+// r^2 == 0 rule is an explicit select here (one v_cndmask_b32).
 __device__ __forceinline__ void pair_f32(double xi, double yi, double zi, double xj, double yj,
-                                         double zj, float mj, double eps2, float& ax, float& ay,
+                                         double zj, float mj, float eps2, float& ax, float& ay,
                                          float& az) {
   const float dx = static_cast<float>(xj - xi);
   const float dy = static_cast<float>(yj - yi);
   const float dz = static_cast<float>(zj - zi);
-  const float r2 =
-      __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, __builtin_fmaf(dx, dx, static_cast<float>(eps2))));
+  const float r2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, __builtin_fmaf(dx, dx, eps2)));
   const float y0 = __builtin_amdgcn_rsqf(r2);
-  const float s = (mj * y0) * (y0 * y0);
+  const float s3 = (mj * y0) * (y0 * y0);
+  const float s = (r2 > 0.0f) ? s3 : 0.0f;
   ax = __builtin_fmaf(s, dx, ax);
   ay = __builtin_fmaf(s, dy, ay);
   az = __builtin_fmaf(s, dz, az);
@@ -105,7 +107,7 @@ struct AccOps<float> {
   static __device__ __forceinline__ void pair(double xi, double yi, double zi, const JBody& b,
                                               double eps2, double, double, float& ax, float& ay,
                                               float& az) {
-    pair_f32(xi, yi, zi, b.x, b.y, b.z, static_cast<float>(b.m), eps2, ax, ay, az);
+    pair_f32(xi, yi, zi, b.x, b.y, b.z, static_cast<float>(b.m), static_cast<float>(eps2), ax, ay, az);
   }
 };
 
@@ -136,7 +138,8 @@ __global__ __launch_bounds__(kTile) void step_kernel(const nbody_mi355x_step_arg
   __shared__ JBody tile[2][kTile];
   const int tid = threadIdx.x;
   const int64_t S = a.shard_slots;
-  const double eps2 = (a.eps2 > 0.0) ? a.eps2 : kTinyR2;
+  // double path: 2^-600 stands in for "no softening" (see kTinyR2); float path: plain 0
+  const double eps2 = (a.eps2 > 0.0) ? a.eps2 : (sizeof(Acc) == sizeof(double) ? kTinyR2 : 0.0);
   double c15 = 1.5, c1875 = 1.875;  // opaque to the optimiser: stay in VGPRs (see pair_f64)
   asm volatile("" : "+v"(c15), "+v"(c1875));
 

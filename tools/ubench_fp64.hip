@@ -10,13 +10,13 @@
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
 constexpr int CH = 8;       // independent chains per lane
-constexpr int ITERS = 2048;  // loop trips; CH ops of the measured kind per trip
+constexpr int ITERS = 16384;  // loop trips; CH ops of the measured kind per trip
 
-enum Op { FMA64, MUL64, ADD64, RSQ64, RCP64, SQRT64HW, CVT_PAIR, RSQ32, FMA32, PKFMA32, MIX_PAIR, NOPS };
+enum Op { FMA64, MUL64, ADD64, RSQ64, RCP64, SQRT64HW, CVT_PAIR, RSQ32, FMA32, PKFMA32, MIX_PAIR, FMA_RSQ, NOPS };
 static const char* kNames[NOPS] = {"v_fma_f64", "v_mul_f64", "v_add_f64", "v_rsq_f64", "v_rcp_f64", "v_sqrt_f64",
-                                   "v_cvt_f32_f64+v_cvt_f64_f32 (2 ops)", "v_rsq_f32", "v_fma_f32", "v_pk_fma_f32",
-                                   "pair_f64 body (16 fp64 + rsq)"};
-static const int kOpsPerChainStep[NOPS] = {1, 1, 1, 1, 1, 1, 2, 1, 1, 1, 17};
+                                   "v_cvt_f32_f64+v_cvt_f64_f32+v_add_f64 (3 ops)", "v_rsq_f32", "v_fma_f32", "v_pk_fma_f32",
+                                   "pair_f64 body (16 fp64 + rsq = 17 instr)", "16 v_fma_f64 + 1 v_rsq_f64 independent"};
+static const int kOpsPerChainStep[NOPS] = {1, 1, 1, 1, 1, 1, 3, 1, 1, 1, 17, 17};
 
 template <int OP>
 __global__ __launch_bounds__(256) void k(double* out, double a, double b) {
@@ -27,7 +27,20 @@ __global__ __launch_bounds__(256) void k(double* out, double a, double b) {
 #pragma unroll
   for (int c = 0; c < CH; c++) { x[c] = 1.0 + 1e-3 * (threadIdx.x + c); f[c] = (float)x[c]; p[c] = f2{f[c], f[c] + 1.f}; }
   double ax = 0, ay = 0, az = 0;
+  double xj = a, yj = b, zj = a + b;
+  double g[16];
+#pragma unroll
+  for (int c = 0; c < 16; c++) g[c] = 1.0 + c;
   for (int it = 0; it < ITERS; it++) {
+    if (OP == MIX_PAIR) { xj += a; yj += b; zj -= a; }  // 3 extra adds per CH pairs (not counted)
+    if (OP == FMA_RSQ) {
+#pragma unroll
+      for (int r = 0; r < CH; r++) {
+        x[r] = __builtin_amdgcn_rsq(x[r]);
+#pragma unroll
+        for (int c = 0; c < 16; c++) g[c] = __builtin_fma(g[c], a, b);
+      }
+    }
 #pragma unroll
     for (int c = 0; c < CH; c++) {
       if (OP == FMA64) x[c] = __builtin_fma(x[c], a, b);
@@ -36,12 +49,12 @@ __global__ __launch_bounds__(256) void k(double* out, double a, double b) {
       if (OP == RSQ64) x[c] = __builtin_amdgcn_rsq(x[c]);
       if (OP == RCP64) x[c] = __builtin_amdgcn_rcp(x[c]);
       if (OP == SQRT64HW) x[c] = __builtin_amdgcn_sqrt(x[c]);
-      if (OP == CVT_PAIR) { float t = (float)x[c]; asm volatile("" : "+v"(t)); x[c] = (double)t; }
+      if (OP == CVT_PAIR) { float t = (float)x[c]; x[c] = (double)t + a; }
       if (OP == RSQ32) f[c] = __builtin_amdgcn_rsqf(f[c]);
       if (OP == FMA32) f[c] = __builtin_fmaf(f[c], (float)a, (float)b);
       if (OP == PKFMA32) p[c] = __builtin_elementwise_fma(p[c], f2{(float)a, (float)a}, f2{(float)b, (float)b});
       if (OP == MIX_PAIR) {
-        const double dx = x[c] - a, dy = x[c] - b, dz = a - x[c];
+        const double dx = xj - x[c], dy = yj - x[c], dz = zj - x[c];
         const double r2 = __builtin_fma(dz, dz, __builtin_fma(dy, dy, __builtin_fma(dx, dx, 0x1p-600)));
         const double y0 = __builtin_amdgcn_rsq(r2);
         const double u = y0 * y0;
@@ -56,6 +69,8 @@ __global__ __launch_bounds__(256) void k(double* out, double a, double b) {
     }
   }
   double s = ax + ay + az;
+#pragma unroll
+  for (int c = 0; c < 16; c++) s += g[c];
 #pragma unroll
   for (int c = 0; c < CH; c++) s += x[c] + f[c] + p[c].x + p[c].y;
   if (s == 123.456) out[0] = s;  // keep everything live, never true
@@ -109,7 +124,7 @@ int main() {
     run<FMA64>(d_out, w, cus); run<MUL64>(d_out, w, cus); run<ADD64>(d_out, w, cus);
     run<RSQ64>(d_out, w, cus); run<RCP64>(d_out, w, cus); run<SQRT64HW>(d_out, w, cus);
     run<CVT_PAIR>(d_out, w, cus); run<RSQ32>(d_out, w, cus); run<FMA32>(d_out, w, cus);
-    run<PKFMA32>(d_out, w, cus); run<MIX_PAIR>(d_out, w, cus);
+    run<PKFMA32>(d_out, w, cus); run<MIX_PAIR>(d_out, w, cus); run<FMA_RSQ>(d_out, w, cus);
     printf("\n");
   }
   const int n = 1 << 22;
