@@ -1,0 +1,127 @@
+// particle_initializer.h -- analytic initial conditions with the reference's call
+// signatures (ref: particle_initializer.h:10-175), plus the large synthetic scenes of
+// libnbody_mi355x.so behind the same InPutParticle type.
+//
+// A body on a (perturbed) circular orbit is built in the XY plane at phase 0 and then
+// turned about X (azimuthal tilt), Y (polar tilt) and Z (phase), in that order, exactly
+// as the reference does; the orbital speed uses G = 6.67430e-11 (ref: :67, :130 -- not
+// the simulator's 6.7430e-11).
+#pragma once
+
+#include <cmath>
+#include <vector>
+
+#include "particle_simulation.h"
+
+template <typename T>
+struct InPutParticle {
+  Particle<T> particle;
+  T m;
+};
+
+// ref: particle_initializer.h:17-42 (names as spelled there).  Each is the plane rotation
+//   p' = p cos(angle) - q sin(angle),  q' = p sin(angle) + q cos(angle)
+// of two components; written out per axis, products in the reference's order, because
+// with -mfma the compiler fuses one product of each sum and WHICH one follows the
+// expression order -- the scene fixtures are compared bit for bit.
+template <typename T>
+void RotateArroundX_Achis(T* vector, T angle) {
+  const T y = vector[1] * cos(angle) - vector[2] * sin(angle);
+  const T z = vector[1] * sin(angle) + vector[2] * cos(angle);
+  vector[1] = y;
+  vector[2] = z;
+}
+template <typename T>
+void RotateArroundY_Achis(T* vector, T angle) {
+  const T x = vector[0] * cos(angle) + vector[2] * sin(angle);
+  const T z = (-1) * vector[0] * sin(angle) + vector[2] * cos(angle);
+  vector[0] = x;
+  vector[2] = z;
+}
+template <typename T>
+void RotateArroundZ_Achis(T* vector, T angle) {
+  const T x = vector[0] * cos(angle) - vector[1] * sin(angle);
+  const T y = vector[0] * sin(angle) + vector[1] * cos(angle);
+  vector[0] = x;
+  vector[1] = y;
+}
+
+// ref: particle_initializer.h:45-54 -- a body at rest at the origin (default: the earth)
+template <typename T>
+InPutParticle<T> BodyAtCenter(T mass = 5.974e+24) {
+  InPutParticle<T> body{};
+  body.m = mass;
+  return body;
+}
+
+// ref: particle_initializer.h:120-175
+template <typename T>
+InPutParticle<T> NonCircularOrbitMoon(T* x_deviation, T* v_deviation, T orbital_phase_z = 0.0,
+                                      T orbital_plane_angle_polar_y = 0.0,
+                                      T orbital_plane_angle_azimutal_x = 0.0, bool clockwise = true,
+                                      T central_body_mass = 5.974e+24, T moon_mass = 7.342e+22,
+                                      T orbital_radius = 3.844e+8) {
+  const T G = 6.67430e-11;
+  const T speed = sqrt((G * central_body_mass) / orbital_radius);
+  InPutParticle<T> body{};
+  T* x = body.particle.r;
+  T* v = body.particle.v;
+  x[0] = orbital_radius + x_deviation[0];
+  x[1] = 0 + x_deviation[1];
+  x[2] = 0 + x_deviation[2];
+  v[0] = 0 + v_deviation[0];
+  v[1] = (clockwise ? speed : -speed) + v_deviation[1];
+  v[2] = 0 + v_deviation[2];
+  if (orbital_plane_angle_azimutal_x != 0.0) {
+    RotateArroundX_Achis(x, orbital_plane_angle_azimutal_x);
+    RotateArroundX_Achis(v, orbital_plane_angle_azimutal_x);
+  }
+  if (orbital_plane_angle_polar_y != 0.0) {
+    RotateArroundY_Achis(x, orbital_plane_angle_polar_y);
+    RotateArroundY_Achis(v, orbital_plane_angle_polar_y);
+  }
+  if (orbital_phase_z != 0.0) {
+    RotateArroundZ_Achis(x, orbital_phase_z);
+    RotateArroundZ_Achis(v, orbital_phase_z);
+  }
+  body.m = moon_mass;
+  return body;
+}
+
+// ref: particle_initializer.h:59-112 -- the unperturbed case
+template <typename T>
+InPutParticle<T> CircularOrbitMoon(T orbital_phase_z = 0.0, T orbital_plane_angle_polar_y = 0.0,
+                                   T orbital_plane_angle_azimutal_x = 0.0, bool clockwise = true,
+                                   T central_body_mass = 5.974e+24, T moon_mass = 7.342e+22,
+                                   T orbital_radius = 3.844e+8) {
+  T none[3] = {0, 0, 0};
+  return NonCircularOrbitMoon<T>(none, none, orbital_phase_z, orbital_plane_angle_polar_y,
+                                 orbital_plane_angle_azimutal_x, clockwise, central_body_mass, moon_mass,
+                                 orbital_radius);
+}
+
+// ---- synthetic scenes (not in the reference): Plummer sphere / cold uniform cube from the
+// library's portable generator, in units G_sim * M_total = 1.
+inline std::vector<InPutParticle<double>> SyntheticScene(bool plummer, int64_t n, uint64_t seed,
+                                                         double G = NBODY_MI355X_G_REFERENCE) {
+  std::vector<double> p(6 * static_cast<size_t>(n)), m(static_cast<size_t>(n));
+  const int rc = plummer ? nbody_mi355x_ic_plummer(n, seed, G, p.data(), m.data())
+                         : nbody_mi355x_ic_uniform_cube(n, seed, G, p.data(), m.data());
+  std::vector<InPutParticle<double>> out;
+  if (rc != NBODY_MI355X_OK) return out;
+  out.resize(static_cast<size_t>(n));
+  for (size_t i = 0; i < out.size(); i++) {
+    for (int c = 0; c < 3; c++) {
+      out[i].particle.r[c] = p[6 * i + c];
+      out[i].particle.v[c] = p[6 * i + 3 + c];
+    }
+    out[i].m = m[i];
+  }
+  return out;
+}
+inline std::vector<InPutParticle<double>> PlummerSphere(int64_t n, uint64_t seed = 42) {
+  return SyntheticScene(true, n, seed);
+}
+inline std::vector<InPutParticle<double>> UniformCube(int64_t n, uint64_t seed = 7) {
+  return SyntheticScene(false, n, seed);
+}
