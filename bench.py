@@ -150,10 +150,13 @@ def main():
                        "bodies": n, "interactions_per_step": inter_per_step,
                        "parallelism": f"i-shard x{world}, RCCL all-gather of positions per step"
                        + ("" if args.no_overlap or world == 1 else ", overlapped with the own-slab half"),
+                       "kernel": ("pair-symmetric tiles + finish" if sim.workspace is not None and args.variant in (0, 12, 14)
+                                  else "one-sided step_kernel"),
                        "kernel_variant": args.variant},
             "roofline": {"bound": "valu_fp64" if prec == nb.FP64 else "valu_fp32", "achieved": round(ach, 3),
                          "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
-                         "kernel": "step_kernel", "avg_launch_ms": round(dev_s / K * 1e3, 3),
+                         "kernel": ("sym_tiles_kernel+sym_finish_kernel" if sim.workspace is not None and args.variant in (0, 12, 14)
+                                    else "step_kernel"), "avg_launch_ms": round(dev_s / K * 1e3, 3),
                          "flop_per_interaction": FLOP_PER_INTERACTION},
             "pct_of_fp64_vector_peak": round(100 * ach / FP64_VECTOR_PEAK_TFLOPS, 2),
         }

@@ -96,8 +96,15 @@ typedef struct {
                              particle_simulation.h:269)                        */
   int32_t precision;      /* NBODY_MI355X_FP64 / _FP32                         */
   int32_t variant;        /* 0 = default kernel choice; >0 selects a specific
-                             kernel build (tuning / A-B benchmarking)          */
+                             kernel build (tuning / A-B benchmarking);
+                             NBODY_MI355X_VARIANT_SYM* = pair-symmetric kernels */
+  void* workspace;        /* device scratch for the pair-symmetric kernels, or
+                             NULL (then only one-sided kernels are used)       */
+  int64_t workspace_bytes;
 } nbody_mi355x_step_args;
+
+#define NBODY_MI355X_VARIANT_SYM2 12 /* pair-symmetric, 512-body blocks  */
+#define NBODY_MI355X_VARIANT_SYM4 14 /* pair-symmetric, 1024-body blocks */
 
 /* One small step (or one half of a split one) for the own slab's bodies:
  * a_i = sum_j m_j (r_j - r_i) / |r_j - r_i|^3 over the j ranges, then
@@ -106,6 +113,14 @@ typedef struct {
  * maths as MakeSmallStep, particle_simulation.h:248-322).  Asynchronous on
  * `stream` (a hipStream_t, NULL = the default stream). */
 int nbody_mi355x_step_f64(const nbody_mi355x_step_args* args, void* stream);
+
+/* Scratch the pair-symmetric form of the step needs for these args (fields
+ * shard_slots, num_shards, variant are read): *bytes = 0 if that form does not
+ * apply (more than one slab, slot count not a multiple of its block, ...).
+ * The symmetric kernels evaluate each unordered pair once (Newton's third law)
+ * and reduce partial sums through this workspace in a fixed order: same maths,
+ * different summation order, bit-reproducible.  No counterpart in the reference. */
+int nbody_mi355x_step_workspace_bytes(const nbody_mi355x_step_args* args, int64_t* bytes);
 
 /* Particle<double>[count] AoS {r[3], v[3]} (ref: particle_simulation.h:20-24)
  * on the device -> own slab's pos (x,y,z runs) + vel, and back.  These are the

@@ -24,73 +24,12 @@
 #include <cstdio>
 #include <cstring>
 
+#include "nbody_device.hpp"
 #include "nbody_internal.h"
 
+using namespace nbody_device;
+
 namespace {
-
-constexpr int kTile = NBODY_MI355X_TILE;  // threads per workgroup == j bodies per tile
-
-struct alignas(32) JBody {
-  double x, y, z, m;
-};
-
-// 2^-600.  With eps2 == 0 the kernel adds this to r^2 inside the first FMA of
-// the r^2 chain.  For any pair a simulation can hold apart (r > 1e-82 in the
-// unit of length) r^2 + 2^-600 rounds to r^2, so the value is bit-for-bit the
-// unsoftened one; for r^2 == 0 (i == j, or coincident bodies) it makes
-// rsq finite (2^300), m * 2^900 stays finite for m < 2^124, and the pair
-// contributes s * 0 = 0: exactly the reference's `if (r_squared != 0)`
-// (particle_simulation.h:269) without a compare or a select.
-constexpr double kTinyR2 = 0x1p-600;
-
-// One interaction in double: 16 FP64 VALU operations + v_rsq_f64:
-//   3 sub, 3 fma (r^2), rsq, 7 for m * r^-3 (below), 3 fma (accumulate).
-// y0 = v_rsq_f64(r2) is only a seed (the ISA promises about 2^-23 relative).  With
-// u = y0^2 and e = 1 - r2*u (one FMA, so e carries just u's rounding) the exact value is
-//   r2^(-3/2) = y0^3 * (1 - e)^(-3/2) = y0^3 * (1 + 3/2 e + 15/8 e^2 + 35/16 e^3 ...)
-// and the series is cut after e^2: the truncation error is 2.2 |e|^3, below
-// 2^-53 for any seed better than 2^-19.  c15/c1875 are 1.5 and 1.875 held in
-// registers by the caller (neither is an inline constant of the ISA; as literals
-// they cost two v_mov per interaction).
-__device__ __forceinline__ void pair_f64(double xi, double yi, double zi, double xj, double yj,
-                                         double zj, double mj, double eps2, double c15,
-                                         double c1875, double& ax, double& ay, double& az) {
-  const double dx = xj - xi;
-  const double dy = yj - yi;
-  const double dz = zj - zi;
-  const double r2 = __builtin_fma(dz, dz, __builtin_fma(dy, dy, __builtin_fma(dx, dx, eps2)));
-  const double y0 = __builtin_amdgcn_rsq(r2);
-  const double u = y0 * y0;
-  const double e = __builtin_fma(-r2, u, 1.0);
-  const double q = mj * y0;
-  const double w = q * u;                       // m * y0^3
-  const double p = __builtin_fma(e, c1875, c15);
-  const double we = w * e;
-  const double s = __builtin_fma(we, p, w);     // m * r^-3
-  ax = __builtin_fma(s, dx, ax);
-  ay = __builtin_fma(s, dy, ay);
-  az = __builtin_fma(s, dz, az);
-}
-
-// Mixed variant: separations in double (so that close pairs of bodies far from the
-// origin do not cancel catastrophically), r^2, r^-3 and the running sums in float.
-// v_rsq_f32 is accurate to ~1 ulp, no correction step.  The 2^-600 trick of the double
-// path does not fit float's exponent range (m * y0^3 would overflow for r^2 -> 0), so the
-// r^2 == 0 rule is an explicit select here (one v_cndmask_b32).
-__device__ __forceinline__ void pair_f32(double xi, double yi, double zi, double xj, double yj,
-                                         double zj, float mj, float eps2, float& ax, float& ay,
-                                         float& az) {
-  const float dx = static_cast<float>(xj - xi);
-  const float dy = static_cast<float>(yj - yi);
-  const float dz = static_cast<float>(zj - zi);
-  const float r2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, __builtin_fmaf(dx, dx, eps2)));
-  const float y0 = __builtin_amdgcn_rsqf(r2);
-  const float s3 = (mj * y0) * (y0 * y0);
-  const float s = (r2 > 0.0f) ? s3 : 0.0f;
-  ax = __builtin_fmaf(s, dx, ax);
-  ay = __builtin_fmaf(s, dy, ay);
-  az = __builtin_fmaf(s, dz, az);
-}
 
 template <typename Acc>
 struct AccOps;
@@ -215,28 +154,7 @@ __global__ __launch_bounds__(kTile) void step_kernel(const nbody_mi355x_step_arg
       a.acc_out[2 * S + li] = azd;
       continue;
     }
-    // ref: particle_simulation.h:288-300.  `v + (dt*a)*G` and `r + dt*v` are each one
-    // FMA, which is also what GCC -O3 -mfma makes of the reference's expressions.
-    const double vx = a.vel[li], vy = a.vel[S + li], vz = a.vel[2 * S + li];
-    const double nvx = __builtin_fma(a.dt * axd, a.G, vx);
-    const double nvy = __builtin_fma(a.dt * ayd, a.G, vy);
-    const double nvz = __builtin_fma(a.dt * azd, a.G, vz);
-    const double nx = __builtin_fma(a.dt, vx, xi[k]);
-    const double ny = __builtin_fma(a.dt, vy, yi[k]);
-    const double nz = __builtin_fma(a.dt, vz, zi[k]);
-    a.vel[li] = nvx;
-    a.vel[S + li] = nvy;
-    a.vel[2 * S + li] = nvz;
-    double* nown = a.pos_next + static_cast<int64_t>(a.own_shard) * 3 * S;
-    nown[li] = nx;
-    nown[S + li] = ny;
-    nown[2 * S + li] = nz;
-    if (a.snapshot != nullptr) {  // ref: particle_simulation.h:304-315 / .cu:127-141
-      double* o = a.snapshot + 9 * li;
-      o[0] = nx; o[1] = ny; o[2] = nz;
-      o[3] = nvx; o[4] = nvy; o[5] = nvz;
-      o[6] = axd * a.G; o[7] = ayd * a.G; o[8] = azd * a.G;
-    }
+    integrate_and_store(a, li, xi[k], yi[k], zi[k], axd, ayd, azd);
   }
 }
 
@@ -379,6 +297,10 @@ extern "C" int nbody_mi355x_device_count(int* count) {
   return NBODY_MI355X_OK;
 }
 
+// Below this many bodies a launch of the symmetric pair of kernels has too few block rows
+// to fill the chip; the one-sided kernel is used.
+static constexpr int64_t kSymMinBodies = 16384;
+
 // Host-side shape checks: everything the kernel's indexing assumes is verified
 // here, before any launch.
 static int check_step_args(const nbody_mi355x_step_args* a) {
@@ -427,6 +349,18 @@ extern "C" int nbody_mi355x_step_f64(const nbody_mi355x_step_args* args, void* s
   if (rc != NBODY_MI355X_OK) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
   hipError_t e;
+  if (args->variant == NBODY_MI355X_VARIANT_SYM2 || args->variant == NBODY_MI355X_VARIANT_SYM4)
+    return nbody_internal::sym_step(*args, s);
+  if (args->variant == 0 && args->workspace != nullptr && args->precision == NBODY_MI355X_FP64 &&
+      args->acc_in == nullptr && args->acc_out == nullptr && args->own_count >= kSymMinBodies &&
+      args->j0_begin == 0 && args->j1_begin == args->j1_end &&
+      args->j0_end >= args->own_count) {
+    // default for large single-slab systems: the pair-symmetric kernels
+    nbody_mi355x_step_args a = *args;
+    a.variant = NBODY_MI355X_VARIANT_SYM4;
+    int64_t need = 0;
+    if (nbody_internal::sym_supported(a, &need) && need <= a.workspace_bytes) return nbody_internal::sym_step(a, s);
+  }
   if (args->precision == NBODY_MI355X_FP32) {
     switch (args->variant) {
       case 1: e = launch_step<1, float, 8>(*args, s); break;
@@ -451,6 +385,15 @@ extern "C" int nbody_mi355x_step_f64(const nbody_mi355x_step_args* args, void* s
     set_error("step launch: %s", hipGetErrorString(e));
     return NBODY_MI355X_ERR_LAUNCH;
   }
+  return NBODY_MI355X_OK;
+}
+
+extern "C" int nbody_mi355x_step_workspace_bytes(const nbody_mi355x_step_args* args, int64_t* bytes) {
+  if (!args || !bytes) { set_error("step_workspace_bytes: null argument"); return NBODY_MI355X_ERR_INVALID; }
+  int64_t b = 0;
+  nbody_mi355x_step_args a = *args;
+  if (a.variant != NBODY_MI355X_VARIANT_SYM2) a.variant = NBODY_MI355X_VARIANT_SYM4;
+  *bytes = nbody_internal::sym_supported(a, &b) ? b : 0;
   return NBODY_MI355X_OK;
 }
 

@@ -27,6 +27,8 @@ struct nbody_mi355x_sim {
   double* mass = nullptr;               // [slots]
   double* aos = nullptr;                // staging: Particle<double>[n] / DeviceOutputParticle<double>[n]
   double* scratch = nullptr;            // energy partials + result
+  void* workspace = nullptr;            // pair-symmetric kernels' partial sums (large N only)
+  int64_t workspace_bytes = 0;
   int cur = 0;
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -55,6 +57,8 @@ int free_all(nbody_mi355x_sim* s) {
     p = nullptr;
   };
   fr(s->pos[0]); fr(s->pos[1]); fr(s->vel); fr(s->mass); fr(s->aos); fr(s->scratch);
+  if (s->workspace && hipFree(s->workspace) != hipSuccess) rc = NBODY_MI355X_ERR_FREE;
+  s->workspace = nullptr;
   if (s->ev0) (void)hipEventDestroy(s->ev0);
   if (s->ev1) (void)hipEventDestroy(s->ev1);
   if (s->stream) (void)hipStreamDestroy(s->stream);
@@ -90,7 +94,8 @@ extern "C" int nbody_mi355x_create(const nbody_mi355x_config* cfg, nbody_mi355x_
   s->cfg = *cfg;
   if (s->cfg.G == 0.0) s->cfg.G = NBODY_MI355X_G_REFERENCE;
   s->n = cfg->num_particles;
-  s->slots = round_up(s->n, NBODY_MI355X_TILE);
+  // large systems: slots in whole 1024-body blocks so that the pair-symmetric kernels apply
+  s->slots = round_up(s->n, s->n >= 8192 ? 1024 : NBODY_MI355X_TILE);
   const size_t slab = sizeof(double) * 3 * static_cast<size_t>(s->slots);
   const int64_t eblocks = s->slots / NBODY_MI355X_TILE;
   bool ok = hipMalloc(&s->pos[0], slab) == hipSuccess && hipMalloc(&s->pos[1], slab) == hipSuccess &&
@@ -106,6 +111,27 @@ extern "C" int nbody_mi355x_create(const nbody_mi355x_config* cfg, nbody_mi355x_
     delete s;
     set_error("create: device allocation failed for N=%lld", (long long)cfg->num_particles);
     return NBODY_MI355X_ERR_ALLOC;
+  }
+  // Workspace of the symmetric kernels: taken only if it fits comfortably (it grows as
+  // N^2 / 1024); without it the one-sided kernel runs, same results to rounding.
+  if (cfg->precision == NBODY_MI355X_FP64) {
+    nbody_mi355x_step_args probe;
+    memset(&probe, 0, sizeof probe);
+    probe.shard_slots = s->slots;
+    probe.num_shards = 1;
+    probe.variant = cfg->variant;
+    int64_t need = 0;
+    size_t free_b = 0, total_b = 0;
+    const bool wanted = cfg->variant == 0 || cfg->variant == NBODY_MI355X_VARIANT_SYM2 ||
+                        cfg->variant == NBODY_MI355X_VARIANT_SYM4;
+    if (wanted && nbody_mi355x_step_workspace_bytes(&probe, &need) == NBODY_MI355X_OK && need > 0 &&
+        hipMemGetInfo(&free_b, &total_b) == hipSuccess && static_cast<size_t>(need) < free_b / 2 &&
+        hipMalloc(&s->workspace, static_cast<size_t>(need)) == hipSuccess) {
+      s->workspace_bytes = need;
+    } else {
+      (void)hipGetLastError();
+      s->workspace = nullptr;
+    }
   }
   *out = s;
   return NBODY_MI355X_OK;
@@ -172,6 +198,8 @@ extern "C" int nbody_mi355x_run(nbody_mi355x_sim* s, int64_t substeps, void* sna
   a.eps2 = s->cfg.eps2;
   a.precision = s->cfg.precision;
   a.variant = s->cfg.variant;
+  a.workspace = s->workspace;
+  a.workspace_bytes = s->workspace_bytes;
   HIP_TRY(hipEventRecord(s->ev0, s->stream), NBODY_MI355X_ERR_LAUNCH, "event record");
   for (int64_t k = 0; k < substeps; k++) {
     a.pos_cur = s->pos[s->cur];

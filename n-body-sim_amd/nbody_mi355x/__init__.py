@@ -46,7 +46,11 @@ class StepArgs(C.Structure):
         ("j0_begin", C.c_int64), ("j0_end", C.c_int64), ("j1_begin", C.c_int64), ("j1_end", C.c_int64),
         ("dt", C.c_double), ("G", C.c_double), ("eps2", C.c_double),
         ("precision", C.c_int32), ("variant", C.c_int32),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
     ]
+
+
+VARIANT_SYM2, VARIANT_SYM4 = 12, 14
 
 
 class Config(C.Structure):
@@ -64,6 +68,7 @@ SYMBOLS = {
     "nbody_mi355x_last_error": (C.c_char_p, []),
     "nbody_mi355x_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "nbody_mi355x_step_f64": (C.c_int, [C.POINTER(StepArgs), _P]),
+    "nbody_mi355x_step_workspace_bytes": (C.c_int, [C.POINTER(StepArgs), C.POINTER(C.c_int64)]),
     "nbody_mi355x_pack_f64": (C.c_int, [_P, C.c_int64, _P, _P, C.c_int64, _P]),
     "nbody_mi355x_unpack_f64": (C.c_int, [_P, _P, C.c_int64, C.c_int64, _P, _P]),
     "nbody_mi355x_energy_f64": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int64,

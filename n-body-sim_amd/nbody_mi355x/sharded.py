@@ -46,8 +46,16 @@ class HipBackend:
         self.precision, self.variant = precision, variant
         self._lib = lib()
 
+    def workspace_bytes(self, S, world):
+        """Scratch the pair-symmetric kernels want for this layout (0: not applicable)."""
+        a = StepArgs()
+        a.shard_slots, a.num_shards, a.variant = S, world, self.variant
+        need = C.c_int64(0)
+        check(self._lib.nbody_mi355x_step_workspace_bytes(C.byref(a), C.byref(need)))
+        return need.value
+
     def step(self, *, pos_cur, pos_next, mass, vel, acc_in, acc_out, snapshot, S, world, rank, count,
-             ranges, dt, G, eps2):
+             ranges, dt, G, eps2, workspace=None):
         a = StepArgs()
         a.pos_cur, a.pos_next, a.mass, a.vel = pos_cur.data_ptr(), pos_next.data_ptr(), mass.data_ptr(), vel.data_ptr()
         a.acc_in = acc_in.data_ptr() if acc_in is not None else None
@@ -57,13 +65,15 @@ class HipBackend:
         (a.j0_begin, a.j0_end), (a.j1_begin, a.j1_end) = ranges
         a.dt, a.G, a.eps2 = dt, G, eps2
         a.precision, a.variant = self.precision, self.variant
+        if workspace is not None:
+            a.workspace, a.workspace_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
         stream = torch.cuda.current_stream(pos_cur.device).cuda_stream
         check(self._lib.nbody_mi355x_step_f64(C.byref(a), C.c_void_p(stream)))
 
 
 class ShardedNBody:
     def __init__(self, particles, mass, dt, *, rank=0, world=1, device="cuda", G=G_REFERENCE, eps2=0.0,
-                 backend=None, overlap=True, group=None):
+                 backend=None, overlap=True, group=None, use_workspace=True):
         particles = np.ascontiguousarray(particles, dtype=np.float64).reshape(-1, 6)
         mass = np.ascontiguousarray(mass, dtype=np.float64)
         self.n, self.rank, self.world = particles.shape[0], rank, world
@@ -73,7 +83,8 @@ class ShardedNBody:
         self.backend = backend if backend is not None else HipBackend()
         self.counts, self.begins = shard_counts(self.n, world)
         self.count = self.counts[rank]
-        self.S = S = round_up(max(self.counts), TILE)
+        # large single-GPU systems: whole 1024-body blocks, so the pair-symmetric kernels apply
+        self.S = S = round_up(max(self.counts), 1024 if (world == 1 and self.n >= 8192) else TILE)
 
         # host image of the slab layout; padding slots: mass 0 at the origin
         pos = np.zeros((world, 3, S))
@@ -92,6 +103,12 @@ class ShardedNBody:
         self.vel = torch.from_numpy(vel).to(dev)
         self.acc = torch.zeros((3, S), dtype=torch.float64, device=dev)
         self.snap = torch.zeros((max(self.count, 1), 9), dtype=torch.float64, device=dev)
+        self.workspace = None
+        if world == 1 and use_workspace and hasattr(self.backend, "workspace_bytes") and self.device.type == "cuda":
+            need = self.backend.workspace_bytes(S, world)
+            free_b, _ = torch.cuda.mem_get_info(self.device)
+            if 0 < need < free_b // 2:
+                self.workspace = torch.empty(need // 8, dtype=torch.float64, device=dev)
         self.cur = 0
         self._fresh = True  # every slab of pos[cur] is current (true right after upload)
 
@@ -103,7 +120,8 @@ class ShardedNBody:
                       count=self.count, dt=self.dt, G=self.G, eps2=self.eps2)
         snap = self.snap if snapshot else None
         if P == 1:
-            self.backend.step(acc_in=None, acc_out=None, snapshot=snap, ranges=((0, self.n), (0, 0)), **common)
+            extra = {"workspace": self.workspace} if self.workspace is not None else {}
+            self.backend.step(acc_in=None, acc_out=None, snapshot=snap, ranges=((0, self.n), (0, 0)), **common, **extra)
         elif not self.overlap or self._fresh:
             if not self._fresh:
                 self._all_gather(cur, async_op=False)
