@@ -101,6 +101,16 @@ typedef struct {
   void* workspace;        /* device scratch for the pair-symmetric kernels, or
                              NULL (then only one-sided kernels are used)       */
   int64_t workspace_bytes;
+  int32_t phase;          /* pair-symmetric kernels only: 0 = the whole force sum;
+                             1 = the part that needs only the own slab's
+                             positions (runs while the all-gather is in flight;
+                             results stay in the workspace); 2 = the rest, then
+                             output.  With num_shards > 1 the output is acc_out
+                             [num_shards][3][shard_slots]: this rank's partial
+                             sums for EVERY slot, to be reduce-scattered and
+                             integrated by a one-sided step with acc_in and
+                             empty j ranges.                                   */
+  int32_t reserved;
 } nbody_mi355x_step_args;
 
 #define NBODY_MI355X_VARIANT_SYM2 12 /* pair-symmetric, 512-body blocks  */

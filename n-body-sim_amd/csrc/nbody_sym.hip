@@ -41,14 +41,19 @@ using nbody_internal::set_error;
 namespace {
 
 struct SymArgs {
-  const double* pos;   // one slab: x[S], y[S], z[S]
-  const double* mass;  // [S]
-  double* R;           // [dsplit][3][S]   i-side sums of row-chunk (I, s)
-  double* C;           // [D][3][S]        j-side sums of tile (I, I+d), indexed by SOURCE row I
-  int64_t S;
-  int nb;      // blocks = S / B
-  int D;       // largest distance = nb / 2
-  int dsplit;  // distance chunks per row
+  const double* pos;   // all slabs, slab layout
+  const double* mass;  // all slabs, flat
+  double* R;           // [nR][3][S]  i-side sums of the own rows, per distance chunk
+  double* C;           // [D][3][S]   j-side sums of tile (I, I+d), indexed by OWN row I - row0
+  int64_t S;           // slots per slab
+  int nbs;             // blocks per slab = S / B
+  int nb;              // blocks in all = num_shards * nbs
+  int row0;            // first own block row = own_shard * nbs
+  int D;               // largest distance = nb / 2
+  int d_lo, d_hi;      // distances this launch covers, inclusive
+  int dsplit;          // chunks [d_lo, d_hi] is cut into (grid.y)
+  int r_base;          // R chunk of this launch's chunk 0
+  int nR;              // R chunks the finishing kernel adds up
   double eps2;
 };
 
@@ -124,6 +129,15 @@ __device__ __forceinline__ void tile_phases(const D2* xy, const D2* zm, double (
   }
 }
 
+// first slot of block J in the slab layout: coordinates via *x (y at +S, z at +2S), mass via *m
+template <int B>
+__device__ __forceinline__ void block_base(const SymArgs& a, int J, const double** x, const double** m) {
+  const int slab = J / a.nbs;
+  const int64_t off = static_cast<int64_t>(J - slab * a.nbs) * B;
+  *x = a.pos + static_cast<int64_t>(slab) * 3 * a.S + off;
+  *m = a.mass + static_cast<int64_t>(slab) * a.S + off;
+}
+
 template <int IPT>
 __global__ __launch_bounds__(256) void sym_tiles_kernel(const SymArgs a) {
   constexpr int B = 256 * IPT;
@@ -132,27 +146,32 @@ __global__ __launch_bounds__(256) void sym_tiles_kernel(const SymArgs a) {
   __shared__ double fJ[3][B];
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int I = blockIdx.x, s = blockIdx.y;
+  const int il = blockIdx.x, s = blockIdx.y;  // own row (local index), distance chunk
+  const int I = a.row0 + il;
   const int64_t S = a.S;
   const double eps2 = (a.eps2 > 0.0) ? a.eps2 : kTinyR2;
   double c15 = 1.5, c1875 = 1.875;
   asm volatile("" : "+v"(c15), "+v"(c1875));
 
   double xi[IPT], yi[IPT], zi[IPT], mi[IPT], ax[IPT], ay[IPT], az[IPT];
+  {
+    const double *px, *pm;
+    block_base<B>(a, I, &px, &pm);
 #pragma unroll
-  for (int k = 0; k < IPT; k++) {
-    const int64_t g = static_cast<int64_t>(I) * B + k * 256 + tid;
-    xi[k] = a.pos[g];
-    yi[k] = a.pos[S + g];
-    zi[k] = a.pos[2 * S + g];
-    mi[k] = a.mass[g];
-    ax[k] = ay[k] = az[k] = 0.0;
+    for (int k = 0; k < IPT; k++) {
+      const int idx = k * 256 + tid;
+      xi[k] = px[idx];
+      yi[k] = px[S + idx];
+      zi[k] = px[2 * S + idx];
+      mi[k] = pm[idx];
+      ax[k] = ay[k] = az[k] = 0.0;
+    }
   }
 
-  const int nd = a.D + 1;  // distances 0 .. D
+  const int nd = a.d_hi - a.d_lo + 1;
   const int chunk = (nd + a.dsplit - 1) / a.dsplit;
-  const int d_begin = s * chunk;
-  const int d_end = (d_begin + chunk < nd) ? d_begin + chunk : nd;
+  const int d_begin = a.d_lo + s * chunk;
+  const int d_end = (d_begin + chunk <= a.d_hi) ? d_begin + chunk : a.d_hi + 1;
 
   for (int d = d_begin; d < d_end; d++) {
     if (2 * d == a.nb && I >= a.nb / 2) continue;  // the antipodal tile belongs to the low rows
@@ -161,15 +180,18 @@ __global__ __launch_bounds__(256) void sym_tiles_kernel(const SymArgs a) {
     const bool sym = (d != 0);
 
     __syncthreads();  // every wave is done with the previous tile's LDS
+    {
+      const double *px, *pm;
+      block_base<B>(a, J, &px, &pm);
 #pragma unroll
-    for (int k = 0; k < IPT; k++) {
-      const int idx = k * 256 + tid;
-      const int64_t g = static_cast<int64_t>(J) * B + idx;
-      xy[idx] = D2{a.pos[g], a.pos[S + g]};
-      zm[idx] = D2{a.pos[2 * S + g], a.mass[g]};
-      fJ[0][idx] = 0.0;
-      fJ[1][idx] = 0.0;
-      fJ[2][idx] = 0.0;
+      for (int k = 0; k < IPT; k++) {
+        const int idx = k * 256 + tid;
+        xy[idx] = D2{px[idx], px[S + idx]};
+        zm[idx] = D2{px[2 * S + idx], pm[idx]};
+        fJ[0][idx] = 0.0;
+        fJ[1][idx] = 0.0;
+        fJ[2][idx] = 0.0;
+      }
     }
     __syncthreads();
 
@@ -177,7 +199,7 @@ __global__ __launch_bounds__(256) void sym_tiles_kernel(const SymArgs a) {
     else tile_phases<IPT, false>(xy, zm, fJ, lane, w, xi, yi, zi, mi, ax, ay, az, eps2, c15, c1875);
 
     if (sym) {
-      double* Cd = a.C + static_cast<int64_t>(d - 1) * 3 * S + static_cast<int64_t>(I) * B;
+      double* Cd = a.C + static_cast<int64_t>(d - 1) * 3 * S + static_cast<int64_t>(il) * B;
 #pragma unroll
       for (int k = 0; k < IPT; k++) {
         const int idx = k * 256 + tid;
@@ -188,7 +210,7 @@ __global__ __launch_bounds__(256) void sym_tiles_kernel(const SymArgs a) {
     }
   }
 
-  double* Rs = a.R + static_cast<int64_t>(s) * 3 * S + static_cast<int64_t>(I) * B;
+  double* Rs = a.R + static_cast<int64_t>(a.r_base + s) * 3 * S + static_cast<int64_t>(il) * B;
 #pragma unroll
   for (int k = 0; k < IPT; k++) {
     const int idx = k * 256 + tid;
@@ -198,61 +220,117 @@ __global__ __launch_bounds__(256) void sym_tiles_kernel(const SymArgs a) {
   }
 }
 
-// a_g = sum_s R[s][g] + sum_d C[d][row J(g) - d][g mod B], fixed order, then the epilogue.
+// Everything this rank has computed for global slot g = (slab, off), added in a fixed order:
+// the own rows' i-side chunks R[s] (own slab only) and, for every own row I that met g's
+// block J at a distance 1 <= d = J - I (mod nb) <= D, the j-side sums C[d][I][.].
+template <int B>
+__device__ __forceinline__ void sum_partials(const SymArgs& sa, int slab, int64_t off, bool own_slab,
+                                             double* ax, double* ay, double* az) {
+  const int64_t S = sa.S;
+  const int J = slab * sa.nbs + static_cast<int>(off / B);
+  const int jl = static_cast<int>(off % B);
+  double x = 0.0, y = 0.0, z = 0.0;
+  if (own_slab) {
+    for (int s = 0; s < sa.nR; s++) {
+      const double* Rs = sa.R + static_cast<int64_t>(s) * 3 * S + off;
+      x += Rs[0];
+      y += Rs[S];
+      z += Rs[2 * S];
+    }
+  }
+  for (int il = 0; il < sa.nbs; il++) {
+    const int I = sa.row0 + il;
+    int d = J - I;
+    if (d < 0) d += sa.nb;
+    if (d < 1 || d > sa.D || (2 * d == sa.nb && I >= sa.nb / 2)) continue;
+    const double* Cd = sa.C + static_cast<int64_t>(d - 1) * 3 * S + static_cast<int64_t>(il) * B + jl;
+    x += Cd[0];
+    y += Cd[S];
+    z += Cd[2 * S];
+  }
+  *ax = x; *ay = y; *az = z;
+}
+
+// one slab: partial sums are complete sums -> integrate directly
 template <int IPT>
 __global__ __launch_bounds__(256) void sym_finish_kernel(const SymArgs sa, const nbody_mi355x_step_args a) {
-  constexpr int B = 256 * IPT;
   const int64_t g = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
   if (g >= a.own_count) return;
   const int64_t S = sa.S;
-  const int J = static_cast<int>(g / B);
-  const int jl = static_cast<int>(g - static_cast<int64_t>(J) * B);
-  double ax = 0.0, ay = 0.0, az = 0.0;
-  for (int s = 0; s < sa.dsplit; s++) {
-    const double* Rs = sa.R + static_cast<int64_t>(s) * 3 * S;
-    ax += Rs[g];
-    ay += Rs[S + g];
-    az += Rs[2 * S + g];
-  }
-  for (int d = 1; d <= sa.D; d++) {
-    int I = J - d;
-    if (I < 0) I += sa.nb;
-    if (2 * d == sa.nb && I >= sa.nb / 2) continue;
-    const double* Cd = sa.C + static_cast<int64_t>(d - 1) * 3 * S + static_cast<int64_t>(I) * B + jl;
-    ax += Cd[0];
-    ay += Cd[S];
-    az += Cd[2 * S];
-  }
+  double ax, ay, az;
+  sum_partials<256 * IPT>(sa, 0, g, true, &ax, &ay, &az);
   integrate_and_store(a, g, a.pos_cur[g], a.pos_cur[S + g], a.pos_cur[2 * S + g], ax, ay, az);
 }
 
+// several slabs (ranks): this rank's partial sums for EVERY slot, [num_shards][3][S]; the
+// caller reduce-scatters them and integrates with an acc_in step.
+template <int IPT>
+__global__ __launch_bounds__(256) void sym_gather_kernel(const SymArgs sa, int own_shard, int num_shards,
+                                                         double* __restrict__ out) {
+  const int64_t S = sa.S;
+  const int64_t g = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (g >= S * num_shards) return;
+  const int slab = static_cast<int>(g / S);
+  const int64_t off = g - static_cast<int64_t>(slab) * S;
+  double ax, ay, az;
+  sum_partials<256 * IPT>(sa, slab, off, slab == own_shard, &ax, &ay, &az);
+  double* o = out + static_cast<int64_t>(slab) * 3 * S + off;
+  o[0] = ax;
+  o[S] = ay;
+  o[2 * S] = az;
+}
+
 struct Plan {
-  int ipt, nb, D, dsplit;
+  int ipt, nbs, nb, D, dsplit;
   int64_t bytes;
 };
 
 bool make_plan(const nbody_mi355x_step_args& a, Plan* p) {
-  p->ipt = (a.variant == 12) ? 2 : 4;
+  p->ipt = (a.variant == NBODY_MI355X_VARIANT_SYM2) ? 2 : 4;
   const int64_t B = 256 * p->ipt;
-  if (a.num_shards != 1 || a.shard_slots % B != 0 || a.shard_slots / B < 2) return false;
-  p->nb = static_cast<int>(a.shard_slots / B);
+  if (a.num_shards < 1 || a.shard_slots <= 0 || a.shard_slots % B != 0) return false;
+  p->nbs = static_cast<int>(a.shard_slots / B);
+  const int64_t nb = static_cast<int64_t>(p->nbs) * a.num_shards;
+  if (nb < 2 || nb > (1 << 24)) return false;
+  p->nb = static_cast<int>(nb);
   p->D = p->nb / 2;
-  const int nd = p->D + 1;
-  int ds = (1024 + p->nb - 1) / p->nb;  // aim at >= 1024 workgroups
-  if (ds > nd) ds = nd;
+  int ds = (1024 + p->nbs - 1) / p->nbs;  // aim at >= 1024 workgroups per launch
+  if (ds > p->D) ds = p->D;
   if (ds < 1) ds = 1;
   p->dsplit = ds;
-  p->bytes = static_cast<int64_t>(sizeof(double)) * 3 * a.shard_slots * (static_cast<int64_t>(ds) + p->D);
+  // R: 1 chunk for the local phase (d = 0) + ds chunks; C: D distances
+  p->bytes = static_cast<int64_t>(sizeof(double)) * 3 * a.shard_slots * (1 + static_cast<int64_t>(ds) + p->D);
   return true;
 }
 
 template <int IPT>
-hipError_t launch(const SymArgs& sa, const nbody_mi355x_step_args& a, hipStream_t stream) {
-  hipLaunchKernelGGL((sym_tiles_kernel<IPT>), dim3(sa.nb, sa.dsplit), dim3(256), 0, stream, sa);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return e;
-  const unsigned blocks = static_cast<unsigned>((a.own_count + 255) / 256);
-  hipLaunchKernelGGL((sym_finish_kernel<IPT>), dim3(blocks), dim3(256), 0, stream, sa, a);
+hipError_t launch(SymArgs sa, const nbody_mi355x_step_args& a, hipStream_t stream) {
+  hipError_t e = hipSuccess;
+  // phase 1 = what needs the own slab only (the diagonal tiles); phase 2 = the rest;
+  // phase 0 = both in one launch
+  const int phase = a.phase;
+  if (phase == 1) {
+    sa.d_lo = 0; sa.d_hi = 0; sa.dsplit = 1; sa.r_base = 0;
+  } else if (phase == 2) {
+    sa.d_lo = 1; sa.d_hi = sa.D; sa.r_base = 1;  // dsplit as planned
+  } else {
+    sa.d_lo = 0; sa.d_hi = sa.D; sa.r_base = 1;  // chunk R[0] unused: zeroed below
+  }
+  if (phase == 0) {
+    e = hipMemsetAsync(sa.R, 0, sizeof(double) * 3 * static_cast<size_t>(sa.S), stream);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL((sym_tiles_kernel<IPT>), dim3(sa.nbs, sa.dsplit), dim3(256), 0, stream, sa);
+  e = hipGetLastError();
+  if (e != hipSuccess || phase == 1) return e;
+  if (a.acc_out != nullptr) {
+    const int64_t total = sa.S * a.num_shards;
+    hipLaunchKernelGGL((sym_gather_kernel<IPT>), dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0,
+                       stream, sa, a.own_shard, a.num_shards, a.acc_out);
+  } else {
+    hipLaunchKernelGGL((sym_finish_kernel<IPT>), dim3(static_cast<unsigned>((a.own_count + 255) / 256)),
+                       dim3(256), 0, stream, sa, a);
+  }
   return hipGetLastError();
 }
 
@@ -270,12 +348,21 @@ bool sym_supported(const nbody_mi355x_step_args& a, int64_t* bytes) {
 int sym_step(const nbody_mi355x_step_args& a, hipStream_t stream) {
   Plan p;
   if (!make_plan(a, &p)) {
-    set_error("symmetric step: needs one slab whose slot count is a multiple of %d and at least two blocks",
-              256 * ((a.variant == 12) ? 2 : 4));
+    set_error("symmetric step: shard_slots must be a multiple of %d and the system at least two blocks",
+              256 * ((a.variant == NBODY_MI355X_VARIANT_SYM2) ? 2 : 4));
     return NBODY_MI355X_ERR_INVALID;
   }
-  if (a.acc_in || a.acc_out || a.j0_begin != 0 || a.j1_begin != a.j1_end || a.precision != NBODY_MI355X_FP64) {
-    set_error("symmetric step: split steps, j sub-ranges and the FP32 variant are one-sided only");
+  if (a.acc_in || a.precision != NBODY_MI355X_FP64) {
+    set_error("symmetric step: acc_in and the FP32 variant are one-sided only");
+    return NBODY_MI355X_ERR_INVALID;
+  }
+  if (a.phase < 0 || a.phase > 2) {
+    set_error("symmetric step: phase %d outside [0,2]", a.phase);
+    return NBODY_MI355X_ERR_INVALID;
+  }
+  if (a.num_shards > 1 && a.phase != 1 && a.acc_out == nullptr) {
+    set_error("symmetric step over %d slabs: acc_out [num_shards][3][shard_slots] is required "
+              "(the partial sums must be reduce-scattered before integrating)", a.num_shards);
     return NBODY_MI355X_ERR_INVALID;
   }
   if (!a.workspace || a.workspace_bytes < p.bytes) {
@@ -287,11 +374,15 @@ int sym_step(const nbody_mi355x_step_args& a, hipStream_t stream) {
   sa.pos = a.pos_cur;
   sa.mass = a.mass;
   sa.R = static_cast<double*>(a.workspace);
-  sa.C = sa.R + static_cast<int64_t>(p.dsplit) * 3 * a.shard_slots;
+  sa.C = sa.R + static_cast<int64_t>(1 + p.dsplit) * 3 * a.shard_slots;
   sa.S = a.shard_slots;
+  sa.nbs = p.nbs;
   sa.nb = p.nb;
+  sa.row0 = a.own_shard * p.nbs;
   sa.D = p.D;
   sa.dsplit = p.dsplit;
+  sa.nR = 1 + p.dsplit;
+  sa.d_lo = sa.d_hi = sa.r_base = 0;
   sa.eps2 = a.eps2;
   const hipError_t e = (p.ipt == 2) ? launch<2>(sa, a, stream) : launch<4>(sa, a, stream);
   if (e != hipSuccess) {

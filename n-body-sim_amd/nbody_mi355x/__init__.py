@@ -47,6 +47,7 @@ class StepArgs(C.Structure):
         ("dt", C.c_double), ("G", C.c_double), ("eps2", C.c_double),
         ("precision", C.c_int32), ("variant", C.c_int32),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
+        ("phase", C.c_int32), ("reserved", C.c_int32),
     ]
 
 

@@ -8,8 +8,13 @@ rank all-gathers the positions it has just updated (velocities stay private;
 no reduction is needed because each rank produces complete a_i).
 
 Layout: the slab layout of include/nbody_mi355x.h, [world][3][S] with
-S = max shard size rounded up to the 256-body tile, so that the exchange is
-ONE in-place all_gather_into_tensor of 3*S doubles per rank.
+S = max shard size rounded up to the 256-body tile (1024 for large systems), so that
+the exchange is ONE in-place all_gather_into_tensor of 3*S doubles per rank.
+
+Large systems use the pair-symmetric kernels: a rank evaluates each unordered pair of
+(own row, block within half the ring ahead) once, which leaves it with partial sums for
+bodies of OTHER ranks; those go home in one reduce_scatter_tensor (3*N doubles in, 3*S
+out) before the Euler update.  Two collectives per step, both tiny next to the tiles.
 
 Overlap: while the collective for small step k is in flight (RCCL runs it on
 its own stream), the rank already accumulates the forces from its OWN slab,
@@ -28,7 +33,9 @@ import ctypes as C
 import numpy as np
 import torch
 
-from . import FP64, G_REFERENCE, TILE, StepArgs, check, lib, round_up
+from . import FP64, G_REFERENCE, TILE, VARIANT_SYM2, VARIANT_SYM4, StepArgs, check, lib, round_up
+
+SYM_MIN_BODIES = 16384  # as kSymMinBodies in csrc/nbody_kernels.hip
 
 
 def shard_counts(n: int, world: int):
@@ -55,7 +62,7 @@ class HipBackend:
         return need.value
 
     def step(self, *, pos_cur, pos_next, mass, vel, acc_in, acc_out, snapshot, S, world, rank, count,
-             ranges, dt, G, eps2, workspace=None):
+             ranges, dt, G, eps2, workspace=None, phase=0, variant=None):
         a = StepArgs()
         a.pos_cur, a.pos_next, a.mass, a.vel = pos_cur.data_ptr(), pos_next.data_ptr(), mass.data_ptr(), vel.data_ptr()
         a.acc_in = acc_in.data_ptr() if acc_in is not None else None
@@ -64,7 +71,8 @@ class HipBackend:
         a.shard_slots, a.num_shards, a.own_shard, a.own_count = S, world, rank, count
         (a.j0_begin, a.j0_end), (a.j1_begin, a.j1_end) = ranges
         a.dt, a.G, a.eps2 = dt, G, eps2
-        a.precision, a.variant = self.precision, self.variant
+        a.precision, a.variant = self.precision, self.variant if variant is None else variant
+        a.phase = phase
         if workspace is not None:
             a.workspace, a.workspace_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
         stream = torch.cuda.current_stream(pos_cur.device).cuda_stream
@@ -83,8 +91,8 @@ class ShardedNBody:
         self.backend = backend if backend is not None else HipBackend()
         self.counts, self.begins = shard_counts(self.n, world)
         self.count = self.counts[rank]
-        # large single-GPU systems: whole 1024-body blocks, so the pair-symmetric kernels apply
-        self.S = S = round_up(max(self.counts), 1024 if (world == 1 and self.n >= 8192) else TILE)
+        # large systems: whole 1024-body blocks, so that the pair-symmetric kernels apply
+        self.S = S = round_up(max(self.counts), 1024 if self.n >= SYM_MIN_BODIES else TILE)
 
         # host image of the slab layout; padding slots: mass 0 at the origin
         pos = np.zeros((world, 3, S))
@@ -103,12 +111,21 @@ class ShardedNBody:
         self.vel = torch.from_numpy(vel).to(dev)
         self.acc = torch.zeros((3, S), dtype=torch.float64, device=dev)
         self.snap = torch.zeros((max(self.count, 1), 9), dtype=torch.float64, device=dev)
+        # pair-symmetric kernels: used when the backend offers them, the
+        # system is large enough and their workspace fits; otherwise the one-sided kernel
         self.workspace = None
-        if world == 1 and use_workspace and hasattr(self.backend, "workspace_bytes") and self.device.type == "cuda":
+        self.acc_all = None
+        variant = getattr(self.backend, "variant", None)
+        if (use_workspace and hasattr(self.backend, "workspace_bytes") and self.device.type == "cuda"
+                and (variant in (VARIANT_SYM2, VARIANT_SYM4) or (variant == 0 and self.n >= SYM_MIN_BODIES))
+                and getattr(self.backend, "precision", FP64) == FP64):
             need = self.backend.workspace_bytes(S, world)
             free_b, _ = torch.cuda.mem_get_info(self.device)
             if 0 < need < free_b // 2:
                 self.workspace = torch.empty(need // 8, dtype=torch.float64, device=dev)
+                if world > 1:
+                    self.acc_all = torch.zeros((world, 3, S), dtype=torch.float64, device=dev)
+        self.sym_variant = VARIANT_SYM2 if variant == VARIANT_SYM2 else VARIANT_SYM4
         self.cur = 0
         self._fresh = True  # every slab of pos[cur] is current (true right after upload)
 
@@ -122,6 +139,10 @@ class ShardedNBody:
         if P == 1:
             extra = {"workspace": self.workspace} if self.workspace is not None else {}
             self.backend.step(acc_in=None, acc_out=None, snapshot=snap, ranges=((0, self.n), (0, 0)), **common, **extra)
+        elif self.workspace is not None:
+            self._sym_forces(cur, common)
+            self._reduce_scatter()
+            self._integrate(common, snap)
         elif not self.overlap or self._fresh:
             if not self._fresh:
                 self._all_gather(cur, async_op=False)
@@ -135,6 +156,29 @@ class ShardedNBody:
                               ranges=((0, r * S), ((r + 1) * S, P * S)), **common)
         self.cur ^= 1
         self._fresh = False
+
+    # -- pair-symmetric step over several ranks, in its three parts (the one-GPU loop-back
+    # test drives them separately): partial sums for EVERY slot -> reduce-scatter -> integrate
+    def _sym_forces(self, cur, common):
+        kw = dict(acc_in=None, snapshot=None, ranges=((0, 0), (0, 0)), workspace=self.workspace,
+                  variant=self.sym_variant, **common)
+        if self.overlap and not self._fresh:
+            work = self._all_gather(cur, async_op=True)             # remote slabs, in flight
+            self.backend.step(acc_out=None, phase=1, **kw)          # diagonal tiles: own slab only
+            work.wait()
+            self.backend.step(acc_out=self.acc_all, phase=2, **kw)  # all other tiles, then gather
+        else:
+            if not self._fresh:
+                self._all_gather(cur, async_op=False)
+            self.backend.step(acc_out=self.acc_all, phase=0, **kw)
+
+    def _reduce_scatter(self):
+        import torch.distributed as dist
+        dist.reduce_scatter_tensor(self.acc.view(-1), self.acc_all.view(-1), group=self.group)
+
+    def _integrate(self, common, snap):
+        # a one-sided step with no j range: acc_in -> Euler update (+ snapshot)
+        self.backend.step(acc_in=self.acc, acc_out=None, snapshot=snap, ranges=((0, 0), (0, 0)), variant=1, **common)
 
     def _all_gather(self, buf, async_op):
         import torch.distributed as dist

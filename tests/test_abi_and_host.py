@@ -26,8 +26,8 @@ def test_header_symbols_all_exported_and_bound():
 
 def test_struct_sizes_match_header_layout():
     import ctypes as C
-    # 7 pointers + int64 + 2 int32 + 5 int64 + 3 double + 2 int32 + pointer + int64
-    assert C.sizeof(nb.StepArgs) == 7 * 8 + 8 + 8 + 5 * 8 + 3 * 8 + 8 + 16
+    # 7 pointers + int64 + 2 int32 + 5 int64 + 3 double + 2 int32 + pointer + int64 + 2 int32
+    assert C.sizeof(nb.StepArgs) == 7 * 8 + 8 + 8 + 5 * 8 + 3 * 8 + 8 + 16 + 8
     assert C.sizeof(nb.Config) == 8 + 3 * 8 + 4 * 4
 
 

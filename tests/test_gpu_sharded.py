@@ -85,3 +85,52 @@ def test_pack_unpack_roundtrip():
     torch.cuda.synchronize()
     assert torch.equal(aos, back)
     assert torch.equal(pos[:, :n], aos[:, :3].T) and torch.all(pos[:, n:] == 0)
+
+
+@pytest.mark.parametrize("world,n", [(2, 20000), (4, 16384), (3, 30000), (8, 65536)])
+def test_symmetric_multi_slab_equals_oracle(world, n):
+    """Pair-symmetric kernels over several slabs: every fake rank computes partial sums
+    for ALL slots, the loop-back 'reduce-scatter' adds them, each rank integrates its slab."""
+    p, m = nb.ic_plummer(n, 13)
+    sims = [ShardedNBody(p, m, 1e-3, rank=r, world=world, device="cuda") for r in range(world)]
+    assert all(s.workspace is not None and s.acc_all is not None for s in sims)
+    grp = LoopbackGroup(sims)
+    steps = 4
+    for k in range(steps):
+        for s in sims:
+            common = dict(pos_cur=s.pos[s.cur], pos_next=s.pos[s.cur ^ 1], mass=s.mass, vel=s.vel, S=s.S,
+                          world=world, rank=s.rank, count=s.count, dt=s.dt, G=s.G, eps2=s.eps2)
+            s._common = common
+            s._sym_forces(s.pos[s.cur], common)          # _fresh is True: no collective inside
+        total = sum(s.acc_all for s in sims)             # what reduce_scatter_tensor would deliver
+        for s in sims:
+            s.acc.copy_(total[s.rank])
+            s._integrate(s._common, s.snap if k == steps - 1 else None)
+            s.cur ^= 1
+        grp.exchange()
+    torch.cuda.synchronize()
+    fin, out = ol.simulate(p, m, 1, steps, 1e-3, threads=16)
+    state = np.concatenate([s.own_state() for s in sims])
+    snap = np.concatenate([s.own_snapshot() for s in sims])
+    assert rel_pos_err(state[:, :3], fin[:, :3]) <= 1e-13
+    num = np.linalg.norm(snap[:, 6:9] - out[0, :, 6:9], axis=1)
+    assert (num / np.linalg.norm(out[0, :, 6:9], axis=1)).max() <= 1e-12
+
+
+def test_symmetric_phases_equal_whole():
+    """phase 1 (diagonal tiles, own slab only) + phase 2 (the rest) == phase 0."""
+    n, world, rank = 40000, 4, 2
+    p, m = nb.ic_plummer(n, 21)
+    s = ShardedNBody(p, m, 1e-3, rank=rank, world=world, device="cuda")
+    common = dict(pos_cur=s.pos[0], pos_next=s.pos[1], mass=s.mass, vel=s.vel, S=s.S, world=world, rank=rank,
+                  count=s.count, dt=s.dt, G=s.G, eps2=0.0)
+    kw = dict(acc_in=None, snapshot=None, ranges=((0, 0), (0, 0)), workspace=s.workspace, variant=nb.VARIANT_SYM4, **common)
+    s.backend.step(acc_out=s.acc_all, phase=0, **kw)
+    whole = s.acc_all.clone()
+    s.acc_all.zero_()
+    s.backend.step(acc_out=None, phase=1, **kw)
+    s.backend.step(acc_out=s.acc_all, phase=2, **kw)
+    torch.cuda.synchronize()
+    scale = whole.abs().max()
+    assert (whole - s.acc_all).abs().max() <= 1e-13 * scale
+    assert whole.abs().max() > 0
