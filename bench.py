@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- Ginteractions/s of the all-pairs hot path (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--n BODIES]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--bodies N]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A "step" is one small step (one pass of the O(N^2) force accumulation + fused Euler
@@ -68,11 +68,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=1048576)
+    ap.add_argument("--bodies", dest="n", type=int, default=1048576)
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--precision", choices=["fp64", "fp32"], default="fp64")
     ap.add_argument("--no-overlap", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
+    ap.add_argument("--share-devices", action="store_true",
+                    help="rehearsal only: ranks share the visible GPUs (device = local_rank %% device_count)")
     args = ap.parse_args()
 
     import torch
@@ -90,11 +93,15 @@ def main():
         sys.exit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (there is no CPU fallback for the product path)")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    dev_index = local_rank % torch.cuda.device_count() if args.share_devices else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     n, K, W = args.n, args.steps, args.warmup
     prec = nb.FP64 if args.precision == "fp64" else nb.FP32
@@ -123,7 +130,7 @@ def main():
     wall = time.perf_counter() - t0
     dev_s = ev0.elapsed_time(ev1) * 1e-3
     if world > 1:
-        t = torch.tensor([wall, dev_s], dtype=torch.float64, device=device)
+        t = torch.tensor([wall, dev_s], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall, dev_s = float(t[0]), float(t[1])
 
@@ -148,14 +155,16 @@ def main():
             "vs_baseline": None, "dtype": "f64" if prec == nb.FP64 else "f32", "data": "synthetic",
             "config": {"workload": f"plummer_sphere_n{n}_{args.precision}_seed42_dt1e-3",
                        "bodies": n, "interactions_per_step": inter_per_step,
-                       "parallelism": f"i-shard x{world}, RCCL all-gather of positions per step"
-                       + ("" if args.no_overlap or world == 1 else ", overlapped with the own-slab half"),
-                       "kernel": ("pair-symmetric tiles + finish" if sim.workspace is not None and args.variant in (0, 12, 14)
+                       "parallelism": (f"i-shard x{world}, RCCL all-gather of positions"
+                                       + (" + reduce-scatter of pair-symmetric partial sums" if sim.acc_all is not None else "")
+                                       + " per step"
+                                       + ("" if args.no_overlap or world == 1 else ", all-gather overlapped with the own-slab part")),
+                       "kernel": ("pair-symmetric tiles + finish" if sim.workspace is not None and args.variant in (0, 10, 11, 12, 14)
                                   else "one-sided step_kernel"),
                        "kernel_variant": args.variant},
             "roofline": {"bound": "valu_fp64" if prec == nb.FP64 else "valu_fp32", "achieved": round(ach, 3),
                          "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
-                         "kernel": ("sym_tiles_kernel+sym_finish_kernel" if sim.workspace is not None and args.variant in (0, 12, 14)
+                         "kernel": ("sym_tiles_kernel+sym_finish_kernel" if sim.workspace is not None and args.variant in (0, 10, 11, 12, 14)
                                     else "step_kernel"), "avg_launch_ms": round(dev_s / K * 1e3, 3),
                          "flop_per_interaction": FLOP_PER_INTERACTION},
             "pct_of_fp64_vector_peak": round(100 * ach / FP64_VECTOR_PEAK_TFLOPS, 2),

@@ -113,6 +113,8 @@ typedef struct {
   int32_t reserved;
 } nbody_mi355x_step_args;
 
+#define NBODY_MI355X_VARIANT_SYM  10 /* pair-symmetric, block size chosen by the library */
+#define NBODY_MI355X_VARIANT_SYM1 11 /* pair-symmetric, 256-body blocks  */
 #define NBODY_MI355X_VARIANT_SYM2 12 /* pair-symmetric, 512-body blocks  */
 #define NBODY_MI355X_VARIANT_SYM4 14 /* pair-symmetric, 1024-body blocks */
 

@@ -297,9 +297,10 @@ extern "C" int nbody_mi355x_device_count(int* count) {
   return NBODY_MI355X_OK;
 }
 
-// Below this many bodies a launch of the symmetric pair of kernels has too few block rows
-// to fill the chip; the one-sided kernel is used.
-static constexpr int64_t kSymMinBodies = 16384;
+// Below this many bodies the one-sided kernel is used by default (measured cross-over on
+// MI355X is below 4096 bodies: 226 vs 77 Ginteractions/s there; both are launch-bound
+// further down, and the one-sided kernel keeps the reference's summation order).
+static constexpr int64_t kSymMinBodies = 2048;
 
 // Host-side shape checks: everything the kernel's indexing assumes is verified
 // here, before any launch.
@@ -349,7 +350,8 @@ extern "C" int nbody_mi355x_step_f64(const nbody_mi355x_step_args* args, void* s
   if (rc != NBODY_MI355X_OK) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
   hipError_t e;
-  if (args->variant == NBODY_MI355X_VARIANT_SYM2 || args->variant == NBODY_MI355X_VARIANT_SYM4)
+  if (args->variant >= NBODY_MI355X_VARIANT_SYM && args->variant <= NBODY_MI355X_VARIANT_SYM4 &&
+      args->variant != 13)
     return nbody_internal::sym_step(*args, s);
   if (args->variant == 0 && args->workspace != nullptr && args->precision == NBODY_MI355X_FP64 &&
       args->acc_in == nullptr && args->acc_out == nullptr && args->own_count >= kSymMinBodies &&
@@ -357,7 +359,7 @@ extern "C" int nbody_mi355x_step_f64(const nbody_mi355x_step_args* args, void* s
       args->j0_end >= args->own_count) {
     // default for large single-slab systems: the pair-symmetric kernels
     nbody_mi355x_step_args a = *args;
-    a.variant = NBODY_MI355X_VARIANT_SYM4;
+    a.variant = NBODY_MI355X_VARIANT_SYM;
     int64_t need = 0;
     if (nbody_internal::sym_supported(a, &need) && need <= a.workspace_bytes) return nbody_internal::sym_step(a, s);
   }
@@ -392,7 +394,9 @@ extern "C" int nbody_mi355x_step_workspace_bytes(const nbody_mi355x_step_args* a
   if (!args || !bytes) { set_error("step_workspace_bytes: null argument"); return NBODY_MI355X_ERR_INVALID; }
   int64_t b = 0;
   nbody_mi355x_step_args a = *args;
-  if (a.variant != NBODY_MI355X_VARIANT_SYM2) a.variant = NBODY_MI355X_VARIANT_SYM4;
+  if (a.variant != NBODY_MI355X_VARIANT_SYM1 && a.variant != NBODY_MI355X_VARIANT_SYM2 &&
+      a.variant != NBODY_MI355X_VARIANT_SYM4)
+    a.variant = NBODY_MI355X_VARIANT_SYM;
   *bytes = nbody_internal::sym_supported(a, &b) ? b : 0;
   return NBODY_MI355X_OK;
 }

@@ -122,8 +122,8 @@ extern "C" int nbody_mi355x_create(const nbody_mi355x_config* cfg, nbody_mi355x_
     probe.variant = cfg->variant;
     int64_t need = 0;
     size_t free_b = 0, total_b = 0;
-    const bool wanted = cfg->variant == 0 || cfg->variant == NBODY_MI355X_VARIANT_SYM2 ||
-                        cfg->variant == NBODY_MI355X_VARIANT_SYM4;
+    const bool wanted = cfg->variant == 0 || (cfg->variant >= NBODY_MI355X_VARIANT_SYM &&
+                                              cfg->variant <= NBODY_MI355X_VARIANT_SYM4);
     if (wanted && nbody_mi355x_step_workspace_bytes(&probe, &need) == NBODY_MI355X_OK && need > 0 &&
         hipMemGetInfo(&free_b, &total_b) == hipSuccess && static_cast<size_t>(need) < free_b / 2 &&
         hipMalloc(&s->workspace, static_cast<size_t>(need)) == hipSuccess) {

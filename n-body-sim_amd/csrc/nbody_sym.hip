@@ -168,10 +168,10 @@ __global__ __launch_bounds__(256) void sym_tiles_kernel(const SymArgs a) {
     }
   }
 
+  // distances [d_lo, d_hi] cut into dsplit chunks whose sizes differ by at most one
   const int nd = a.d_hi - a.d_lo + 1;
-  const int chunk = (nd + a.dsplit - 1) / a.dsplit;
-  const int d_begin = a.d_lo + s * chunk;
-  const int d_end = (d_begin + chunk <= a.d_hi) ? d_begin + chunk : a.d_hi + 1;
+  const int d_begin = a.d_lo + static_cast<int>(static_cast<int64_t>(s) * nd / a.dsplit);
+  const int d_end = a.d_lo + static_cast<int>(static_cast<int64_t>(s + 1) * nd / a.dsplit);
 
   for (int d = d_begin; d < d_end; d++) {
     if (2 * d == a.nb && I >= a.nb / 2) continue;  // the antipodal tile belongs to the low rows
@@ -285,22 +285,62 @@ struct Plan {
   int64_t bytes;
 };
 
-bool make_plan(const nbody_mi355x_step_args& a, Plan* p) {
-  p->ipt = (a.variant == NBODY_MI355X_VARIANT_SYM2) ? 2 : 4;
-  const int64_t B = 256 * p->ipt;
-  if (a.num_shards < 1 || a.shard_slots <= 0 || a.shard_slots % B != 0) return false;
+// One candidate block size: fills *p and returns its modelled time (arbitrary units), or a
+// negative value if it does not apply.
+double plan_for(const nbody_mi355x_step_args& a, int ipt, Plan* p) {
+  const int64_t B = 256 * ipt;
+  if (a.num_shards < 1 || a.shard_slots <= 0 || a.shard_slots % B != 0) return -1.0;
+  p->ipt = ipt;
   p->nbs = static_cast<int>(a.shard_slots / B);
   const int64_t nb = static_cast<int64_t>(p->nbs) * a.num_shards;
-  if (nb < 2 || nb > (1 << 24)) return false;
+  if (nb < 2 || nb > (1 << 24)) return -1.0;
   p->nb = static_cast<int>(nb);
   p->D = p->nb / 2;
-  int ds = (1024 + p->nbs - 1) / p->nbs;  // aim at >= 1024 workgroups per launch
+  // Every row has D+1 equal tiles, cut into ds chunks -> nbs*ds workgroups per launch, up to
+  // `per_cu` of them resident on a CU (LDS / VGPR budget of the kernel build), each getting
+  // 1/k of the CU when k share it.  Critical path = rounds * tiles-per-workgroup * k * tile
+  // cost; a lone workgroup (k = 1, one wave per SIMD) cannot keep the FP64 pipe full.
+  const int per_cu = ipt == 4 ? 2 : (ipt == 2 ? 4 : 8);
+  const double pair_cost = ipt == 4 ? 1.00 : (ipt == 2 ? 1.06 : 1.17);  // DPP + addressing per pair
+  const int nd = p->D + 1;
+  int ds = 1;
+  double best = -1.0;
+  for (int c = 1; c <= nd && c <= 64; c++) {
+    const int64_t wgs = static_cast<int64_t>(p->nbs) * c;
+    const int64_t rounds = (wgs + 256 * per_cu - 1) / (256 * per_cu);
+    int64_t k = (wgs + 255) / 256;
+    if (k > per_cu) k = per_cu;
+    const double lone = k == 1 ? 1.5 : 1.0;
+    const double t = static_cast<double>(rounds) * ((nd + c - 1) / c) * static_cast<double>(k) * lone *
+                     static_cast<double>(B) * static_cast<double>(B) * pair_cost;
+    if (best < 0.0 || t < best) { best = t; ds = c; }
+  }
   if (ds > p->D) ds = p->D;
   if (ds < 1) ds = 1;
   p->dsplit = ds;
   // R: 1 chunk for the local phase (d = 0) + ds chunks; C: D distances
   p->bytes = static_cast<int64_t>(sizeof(double)) * 3 * a.shard_slots * (1 + static_cast<int64_t>(ds) + p->D);
-  return true;
+  return best;
+}
+
+// The plan is a pure function of (shard_slots, num_shards, variant): the workspace query
+// and the step agree on it.
+bool make_plan(const nbody_mi355x_step_args& a, Plan* p) {
+  if (a.variant == NBODY_MI355X_VARIANT_SYM1) return plan_for(a, 1, p) >= 0.0;
+  if (a.variant == NBODY_MI355X_VARIANT_SYM2) return plan_for(a, 2, p) >= 0.0;
+  if (a.variant == NBODY_MI355X_VARIANT_SYM4) return plan_for(a, 4, p) >= 0.0;
+  // automatic: the fastest block size by the model whose workspace stays moderate
+  // (it grows as N^2 / block; the largest block is always allowed)
+  const int64_t cap = int64_t{16} << 30;
+  bool found = false;
+  double best = 0.0;
+  for (int ipt : {4, 2, 1}) {
+    Plan c;
+    const double t = plan_for(a, ipt, &c);
+    if (t < 0.0 || (ipt != 4 && c.bytes > cap)) continue;
+    if (!found || t < best) { found = true; best = t; *p = c; }
+  }
+  return found;
 }
 
 template <int IPT>
@@ -348,8 +388,8 @@ bool sym_supported(const nbody_mi355x_step_args& a, int64_t* bytes) {
 int sym_step(const nbody_mi355x_step_args& a, hipStream_t stream) {
   Plan p;
   if (!make_plan(a, &p)) {
-    set_error("symmetric step: shard_slots must be a multiple of %d and the system at least two blocks",
-              256 * ((a.variant == NBODY_MI355X_VARIANT_SYM2) ? 2 : 4));
+    set_error("symmetric step: shard_slots must be a multiple of the block (256, 512 or 1024 by variant) "
+              "and the system at least two blocks");
     return NBODY_MI355X_ERR_INVALID;
   }
   if (a.acc_in || a.precision != NBODY_MI355X_FP64) {
@@ -384,7 +424,8 @@ int sym_step(const nbody_mi355x_step_args& a, hipStream_t stream) {
   sa.nR = 1 + p.dsplit;
   sa.d_lo = sa.d_hi = sa.r_base = 0;
   sa.eps2 = a.eps2;
-  const hipError_t e = (p.ipt == 2) ? launch<2>(sa, a, stream) : launch<4>(sa, a, stream);
+  const hipError_t e = p.ipt == 1 ? launch<1>(sa, a, stream)
+                       : p.ipt == 2 ? launch<2>(sa, a, stream) : launch<4>(sa, a, stream);
   if (e != hipSuccess) {
     set_error("symmetric step launch: %s", hipGetErrorString(e));
     return NBODY_MI355X_ERR_LAUNCH;

@@ -33,9 +33,10 @@ import ctypes as C
 import numpy as np
 import torch
 
-from . import FP64, G_REFERENCE, TILE, VARIANT_SYM2, VARIANT_SYM4, StepArgs, check, lib, round_up
+from . import FP64, G_REFERENCE, TILE, VARIANT_SYM, VARIANT_SYM1, VARIANT_SYM2, VARIANT_SYM4, StepArgs, check, lib, round_up
 
-SYM_MIN_BODIES = 16384  # as kSymMinBodies in csrc/nbody_kernels.hip
+SYM_MIN_BODIES = 2048  # as kSymMinBodies in csrc/nbody_kernels.hip
+SYM_VARIANTS = (VARIANT_SYM, VARIANT_SYM1, VARIANT_SYM2, VARIANT_SYM4)
 
 
 def shard_counts(n: int, world: int):
@@ -92,7 +93,7 @@ class ShardedNBody:
         self.counts, self.begins = shard_counts(self.n, world)
         self.count = self.counts[rank]
         # large systems: whole 1024-body blocks, so that the pair-symmetric kernels apply
-        self.S = S = round_up(max(self.counts), 1024 if self.n >= SYM_MIN_BODIES else TILE)
+        self.S = S = round_up(max(self.counts), 1024 if max(self.counts) >= 8192 else TILE)
 
         # host image of the slab layout; padding slots: mass 0 at the origin
         pos = np.zeros((world, 3, S))
@@ -117,7 +118,7 @@ class ShardedNBody:
         self.acc_all = None
         variant = getattr(self.backend, "variant", None)
         if (use_workspace and hasattr(self.backend, "workspace_bytes") and self.device.type == "cuda"
-                and (variant in (VARIANT_SYM2, VARIANT_SYM4) or (variant == 0 and self.n >= SYM_MIN_BODIES))
+                and (variant in SYM_VARIANTS or (variant == 0 and self.n >= SYM_MIN_BODIES))
                 and getattr(self.backend, "precision", FP64) == FP64):
             need = self.backend.workspace_bytes(S, world)
             free_b, _ = torch.cuda.mem_get_info(self.device)
@@ -125,7 +126,7 @@ class ShardedNBody:
                 self.workspace = torch.empty(need // 8, dtype=torch.float64, device=dev)
                 if world > 1:
                     self.acc_all = torch.zeros((world, 3, S), dtype=torch.float64, device=dev)
-        self.sym_variant = VARIANT_SYM2 if variant == VARIANT_SYM2 else VARIANT_SYM4
+        self.sym_variant = variant if variant in SYM_VARIANTS else VARIANT_SYM
         self.cur = 0
         self._fresh = True  # every slab of pos[cur] is current (true right after upload)
 
@@ -174,7 +175,12 @@ class ShardedNBody:
 
     def _reduce_scatter(self):
         import torch.distributed as dist
-        dist.reduce_scatter_tensor(self.acc.view(-1), self.acc_all.view(-1), group=self.group)
+        if dist.get_backend(self.group) == "nccl":   # RCCL
+            dist.reduce_scatter_tensor(self.acc.view(-1), self.acc_all.view(-1), group=self.group)
+        else:  # gloo (rehearsals without one GPU per rank): no reduce_scatter; staged via the host
+            host = self.acc_all.cpu()
+            dist.all_reduce(host, group=self.group)
+            self.acc.copy_(host[self.rank])
 
     def _integrate(self, common, snap):
         # a one-sided step with no j range: acc_in -> Euler update (+ snapshot)
@@ -184,7 +190,21 @@ class ShardedNBody:
         import torch.distributed as dist
         flat = buf.view(-1)
         own = flat[self.rank * 3 * self.S:(self.rank + 1) * 3 * self.S]
-        return dist.all_gather_into_tensor(flat, own, group=self.group, async_op=async_op)
+        if dist.get_backend(self.group) == "nccl" or buf.device.type == "cpu":
+            # in place: the input is this rank's slab inside the output
+            return dist.all_gather_into_tensor(flat, own, group=self.group, async_op=async_op)
+        # gloo with device tensors (rehearsals): staged via the host, out of place
+        mine = own.cpu()
+        parts = [torch.empty_like(mine) for _ in range(self.world)]
+        dist.all_gather(parts, mine, group=self.group)
+        for r, part in enumerate(parts):
+            if r != self.rank:
+                flat[r * 3 * self.S:(r + 1) * 3 * self.S].copy_(part)
+
+        class _Done:
+            def wait(self):
+                return True
+        return _Done()
 
     def sync_positions(self):
         """Make every slab of the current buffer current (needed before reading remote slabs)."""

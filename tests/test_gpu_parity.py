@@ -203,7 +203,8 @@ def test_error_behaviour():
 
 # ----------------------------------------------------------------- pair-symmetric kernels
 @pytest.mark.parametrize("variant,n", [(14, 4096), (12, 4096), (12, 3000), (14, 10000), (14, 11000),
-                                       (14, 2048), (12, 1024), (0, 20000)])
+                                       (14, 2048), (12, 1024), (0, 20000), (11, 700), (11, 5000),
+                                       (10, 9000), (10, 40000)])
 def test_symmetric_kernels_against_oracle(variant, n):
     """Newton's-third-law kernels (each unordered pair once; even and odd block counts,
     ragged last block, the smallest legal systems) against the oracle's ordered-pair sums."""

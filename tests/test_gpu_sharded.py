@@ -33,7 +33,7 @@ class LoopbackGroup:
 @pytest.mark.parametrize("world,n", [(2, 1000), (4, 4096), (3, 777)])
 def test_multi_slab_layout_equals_oracle(world, n):
     p, m = nb.ic_plummer(n, 9)
-    sims = [ShardedNBody(p, m, 1e-3, rank=r, world=world, device="cuda") for r in range(world)]
+    sims = [ShardedNBody(p, m, 1e-3, rank=r, world=world, device="cuda", use_workspace=False) for r in range(world)]
     grp = LoopbackGroup(sims)
     steps = 10
     for k in range(steps):
@@ -53,8 +53,8 @@ def test_split_step_equals_full_step():
     changed summation order."""
     n, world, rank = 3000, 3, 1
     p, m = nb.ic_plummer(n, 11)
-    full = ShardedNBody(p, m, 1e-3, rank=rank, world=world, device="cuda")
-    split = ShardedNBody(p, m, 1e-3, rank=rank, world=world, device="cuda")
+    full = ShardedNBody(p, m, 1e-3, rank=rank, world=world, device="cuda", use_workspace=False)
+    split = ShardedNBody(p, m, 1e-3, rank=rank, world=world, device="cuda", use_workspace=False)
     full.step(snapshot=True)
     # drive the split path by hand (no process group on one device)
     S, P, r = split.S, world, rank
@@ -134,3 +134,61 @@ def test_symmetric_phases_equal_whole():
     scale = whole.abs().max()
     assert (whole - s.acc_all).abs().max() <= 1e-13 * scale
     assert whole.abs().max() > 0
+
+
+def _rank_main(rank, world, port, n, steps, q):
+    """A real rank of the sharded driver (own process, own process group); the two ranks
+    share the one GPU of the test box and talk over gloo, staged through the host."""
+    import os
+    import sys
+    from pathlib import Path
+    repo = Path(__file__).resolve().parent.parent
+    sys.path.insert(0, str(repo / "n-body-sim_amd"))
+    sys.path.insert(0, str(repo / "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import nbody_mi355x as nb
+        from nbody_mi355x.sharded import ShardedNBody
+        p, m = nb.ic_plummer(n, 31)
+        sim = ShardedNBody(p, m, 1e-3, rank=rank, world=world, device="cuda:0", overlap=True)
+        for k in range(steps):
+            sim.step(snapshot=(k == steps - 1))
+        torch.cuda.synchronize()
+        q.put((rank, sim.own_state(), sim.own_snapshot(), sim.workspace is not None))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n,expect_sym", [(1500, False), (20000, True)])
+def test_two_real_ranks_end_to_end(n, expect_sym):
+    """ShardedNBody.step() as bench.py drives it -- collectives, buffer rotation, overlap
+    split (one-sided) and partial-sum exchange (pair-symmetric) -- against the oracle."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    world, steps = 2, 5
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rank_main, args=(r, world, port, n, steps, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    res = sorted((q.get(timeout=100) for _ in range(world)), key=lambda t: t[0])
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    assert all(r[3] == expect_sym for r in res)
+    p, m = nb.ic_plummer(n, 31)
+    fin, out = ol.simulate(p, m, 1, steps, 1e-3, threads=16)
+    state = np.concatenate([r[1] for r in res])
+    snap = np.concatenate([r[2] for r in res])
+    assert rel_pos_err(state[:, :3], fin[:, :3]) <= 1e-13
+    assert rel_pos_err(snap[:, :3], out[0, :, :3]) <= 1e-13
+    num = np.linalg.norm(snap[:, 6:9] - out[0, :, 6:9], axis=1)
+    assert (num / np.linalg.norm(out[0, :, 6:9], axis=1)).max() <= 1e-12
