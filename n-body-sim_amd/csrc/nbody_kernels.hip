@@ -158,6 +158,70 @@ __global__ __launch_bounds__(kTile) void step_kernel(const nbody_mi355x_step_arg
   }
 }
 
+// ---------------------------------------------------------------- small systems
+// Below a few thousand bodies one lane per body leaves the chip empty (N = 500 is eight
+// waves) and a launch is one long serial j loop.  Here a body is shared by a DPP row of 16
+// lanes: lane r of the row takes the j bodies r, r+16, ... of each staged tile, the 16
+// partial sums are added across the row (4 row_shr steps) and lane 15 integrates.  A
+// workgroup is 16 bodies, so N = 500 is 32 workgroups of 4 waves and the j loop is 16 times
+// shorter.  Summation order: 16 interleaved partial sums per body (not the reference's
+// single chain); same per-pair arithmetic.
+__device__ __forceinline__ double row_sum16(double v) {
+  // after the four steps lane 15 of each 16-lane row holds the row's sum
+#define NBODY_ROW_STEP(ctrl)                                                         \
+  {                                                                                  \
+    int lo = __double2loint(v), hi = __double2hiint(v);                              \
+    lo = __builtin_amdgcn_update_dpp(0, lo, ctrl, 0xf, 0xf, true);                   \
+    hi = __builtin_amdgcn_update_dpp(0, hi, ctrl, 0xf, 0xf, true);                   \
+    v += __hiloint2double(hi, lo);                                                   \
+  }
+  NBODY_ROW_STEP(0x111)  // row_shr:1
+  NBODY_ROW_STEP(0x112)  // row_shr:2
+  NBODY_ROW_STEP(0x114)  // row_shr:4
+  NBODY_ROW_STEP(0x118)  // row_shr:8
+#undef NBODY_ROW_STEP
+  return v;
+}
+
+__global__ __launch_bounds__(kTile) void step_small_kernel(const nbody_mi355x_step_args a) {
+  __shared__ JBody tile[2][kTile];
+  const int tid = threadIdx.x;
+  const int r = tid & 15;                                  // j slice of this lane
+  const int64_t S = a.shard_slots;
+  const double eps2 = (a.eps2 > 0.0) ? a.eps2 : kTinyR2;
+  double c15 = 1.5, c1875 = 1.875;
+  asm volatile("" : "+v"(c15), "+v"(c1875));
+
+  const int64_t li = static_cast<int64_t>(blockIdx.x) * 16 + (tid >> 4);  // own body of this row
+  const int64_t lc = li < S ? li : S - 1;
+  const double* own = a.pos_cur + static_cast<int64_t>(a.own_shard) * 3 * S;
+  const double xi = own[lc], yi = own[S + lc], zi = own[2 * S + lc];
+  double ax = 0.0, ay = 0.0, az = 0.0;
+
+  const int64_t ntiles = (a.j0_end - a.j0_begin + kTile - 1) / kTile;
+  if (ntiles > 0) {
+    tile[0][tid] = load_j(a, a.j0_begin, a.j0_end, tid);
+    __syncthreads();
+    for (int64_t t = 0; t < ntiles; t++) {
+      const int buf = static_cast<int>(t & 1);
+      JBody nxt;
+      const bool more = (t + 1) < ntiles;
+      if (more) nxt = load_j(a, a.j0_begin + (t + 1) * kTile, a.j0_end, tid);
+#pragma unroll 4
+      for (int jj = 0; jj < kTile / 16; jj++) {
+        const JBody b = tile[buf][jj * 16 + r];
+        pair_f64(xi, yi, zi, b.x, b.y, b.z, b.m, eps2, c15, c1875, ax, ay, az);
+      }
+      if (more) tile[buf ^ 1][tid] = nxt;
+      __syncthreads();
+    }
+  }
+  ax = row_sum16(ax);
+  ay = row_sum16(ay);
+  az = row_sum16(az);
+  if (r == 15 && li < a.own_count) integrate_and_store(a, li, xi, yi, zi, ax, ay, az);
+}
+
 // ------------------------------------------------------------ layout converters
 __global__ void pack_kernel(const double* __restrict__ aos, int64_t count, double* __restrict__ pos,
                             double* __restrict__ vel, int64_t S) {
@@ -263,6 +327,19 @@ hipError_t launch_step(const nbody_mi355x_step_args& a, hipStream_t stream) {
   if (blocks <= 0) return hipSuccess;
   hipLaunchKernelGGL((step_kernel<IPT, Acc, UNROLL>), dim3(static_cast<unsigned>(blocks)), dim3(kTile),
                      0, stream, a);
+  return hipGetLastError();
+}
+
+// The small-system kernel handles whole, unsplit steps over one j range.
+bool small_applies(const nbody_mi355x_step_args& a) {
+  return a.acc_in == nullptr && a.acc_out == nullptr && a.j1_begin == a.j1_end &&
+         a.precision == NBODY_MI355X_FP64 && a.own_count <= 4096 && a.own_count > 0;
+}
+
+hipError_t launch_small(const nbody_mi355x_step_args& a, hipStream_t stream) {
+  if (!small_applies(a)) return hipErrorInvalidValue;
+  const unsigned blocks = static_cast<unsigned>((a.own_count + 15) / 16);
+  hipLaunchKernelGGL(step_small_kernel, dim3(blocks), dim3(kTile), 0, stream, a);
   return hipGetLastError();
 }
 
@@ -376,7 +453,9 @@ extern "C" int nbody_mi355x_step_f64(const nbody_mi355x_step_args* args, void* s
       case 3: e = launch_step<1, double, 4>(*args, s); break;
       case 4: e = launch_step<4, double, 2>(*args, s); break;
       case 5: e = launch_step<2, double, 8>(*args, s); break;
+      case 6: e = launch_small(*args, s); break;
       default:
+        if (small_applies(*args)) { e = launch_small(*args, s); break; }
         // enough workgroups to give every SIMD >= 2 waves with 2 bodies per lane?
         if (args->own_count >= 2 * 256 * 4 * 2 * 64) e = launch_step<2, double, 4>(*args, s);
         else e = launch_step<1, double, 8>(*args, s);

@@ -33,6 +33,9 @@ struct nbody_mi355x_sim {
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   double last_run_seconds = 0.0;
+  // launch-bound sizes: kGraphSteps small steps captured once per buffer parity and replayed
+  hipGraphExec_t graph[2] = {nullptr, nullptr};
+  bool graph_failed = false;
   std::vector<double> host_tmp;  // float <-> double conversion of host records
 };
 
@@ -50,6 +53,14 @@ namespace {
 
 int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
 
+// Small systems are launch-bound (a small step of N = 500 is a few microseconds of GPU
+// work): the substep loop of a big step is replayed from a hipGraph of kGraphSteps steps
+// (even, so that the current/next buffers end where they started) instead of being
+// launched one kernel at a time from the host.  The reference launches AND synchronises
+// per substep (particle_simulation_GPU.cu:149-155).
+constexpr int kGraphSteps = 64;
+constexpr int64_t kGraphMaxBodies = 16384;
+
 int free_all(nbody_mi355x_sim* s) {
   int rc = NBODY_MI355X_OK;
   auto fr = [&](double*& p) {
@@ -59,6 +70,10 @@ int free_all(nbody_mi355x_sim* s) {
   fr(s->pos[0]); fr(s->pos[1]); fr(s->vel); fr(s->mass); fr(s->aos); fr(s->scratch);
   if (s->workspace && hipFree(s->workspace) != hipSuccess) rc = NBODY_MI355X_ERR_FREE;
   s->workspace = nullptr;
+  for (auto& g : s->graph) {
+    if (g) (void)hipGraphExecDestroy(g);
+    g = nullptr;
+  }
   if (s->ev0) (void)hipEventDestroy(s->ev0);
   if (s->ev1) (void)hipEventDestroy(s->ev1);
   if (s->stream) (void)hipStreamDestroy(s->stream);
@@ -201,7 +216,38 @@ extern "C" int nbody_mi355x_run(nbody_mi355x_sim* s, int64_t substeps, void* sna
   a.workspace = s->workspace;
   a.workspace_bytes = s->workspace_bytes;
   HIP_TRY(hipEventRecord(s->ev0, s->stream), NBODY_MI355X_ERR_LAUNCH, "event record");
-  for (int64_t k = 0; k < substeps; k++) {
+  int64_t k = 0;
+  const int64_t replayable = substeps - (snapshot_out ? 1 : 0);  // the snapshot step is launched plainly
+  if (s->n <= kGraphMaxBodies && replayable >= 2 * kGraphSteps && !s->graph_failed) {
+    hipGraphExec_t& exec = s->graph[s->cur];
+    if (!exec) {
+      hipGraph_t graph = nullptr;
+      bool ok = hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+      int rc = NBODY_MI355X_OK;
+      if (ok) {
+        a.snapshot = nullptr;
+        int c = s->cur;
+        for (int g = 0; g < kGraphSteps && rc == NBODY_MI355X_OK; g++, c ^= 1) {
+          a.pos_cur = s->pos[c];
+          a.pos_next = s->pos[c ^ 1];
+          rc = nbody_mi355x_step_f64(&a, s->stream);
+        }
+        ok = hipStreamEndCapture(s->stream, &graph) == hipSuccess && rc == NBODY_MI355X_OK && graph != nullptr;
+      }
+      if (ok) ok = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess;
+      if (graph) (void)hipGraphDestroy(graph);
+      if (!ok) {  // not fatal: plain launches below do the same work
+        (void)hipGetLastError();
+        exec = nullptr;
+        s->graph_failed = true;
+      }
+    }
+    while (exec && k + kGraphSteps <= replayable) {
+      HIP_TRY(hipGraphLaunch(exec, s->stream), NBODY_MI355X_ERR_LAUNCH, "graph launch");
+      k += kGraphSteps;  // an even number of steps: s->cur is unchanged
+    }
+  }
+  for (; k < substeps; k++) {
     a.pos_cur = s->pos[s->cur];
     a.pos_next = s->pos[s->cur ^ 1];
     a.snapshot = (snapshot_out && k == substeps - 1) ? s->aos : nullptr;

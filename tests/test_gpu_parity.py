@@ -73,7 +73,7 @@ def test_single_force_evaluation_accuracy():
     assert vec_rel(out[0, :, 6:9], g["out_cpu"][0, :, 6:9]) <= 1e-13
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6])
 def test_every_kernel_build_agrees(variant):
     g = load_golden("g4_plummer_1024")
     _, out = gpu_simulate(g["particles"], g["mass"], 1, 100, float(g["dt"]), variant=variant)
@@ -170,6 +170,19 @@ def test_mid_size_full_trajectory_against_oracle():
     assert rel_pos_err(out[0, :, :3], ref[0, :, :3]) <= 1e-11
 
 
+def test_config3_plummer_65536_full_trajectory():
+    """BASELINE config 3 at full size: Plummer N = 65 536, 100 small steps, the WHOLE
+    trajectory.  SimulateCPU() would need minutes here, so the comparator is the oracle's
+    SimulateAVX2() restatement (bit-identical to the reference's AVX2 path on the golden
+    vectors, and within 6e-12 of its scalar path per SURVEY section 4): ~20 s on 16 threads."""
+    n = 65536
+    p, m = nb.ic_plummer(n, 42)
+    _, ref = ol.simulate(p, m, 1, 100, 1e-3, threads=16, kind="avx2")
+    _, out = gpu_simulate(p, m, 1, 100, 1e-3)
+    assert rel_pos_err(out[0, :, :3], ref[0, :, :3]) <= FP64_TOL
+    assert rel_pos_err(out[0, :, :3], ref[0, :, :3]) <= 1e-11
+
+
 @pytest.mark.parametrize("n", [65536, 1048576])
 def test_full_size_sampled_rows_and_momentum(n):
     """BASELINE sizes: the oracle cannot run the full step, so (a) exact accelerations for
@@ -244,3 +257,17 @@ def test_symmetric_softening():
     r2 = (d ** 2).sum(-1) + eps2
     a = nb.G_REFERENCE * (m[None, :, None] * d / r2[..., None] ** 1.5).sum(1)
     assert vec_rel(out[0, :, 6:9], a) <= 1e-13
+
+
+def test_graph_replayed_substeps_match_oracle():
+    """Many small steps of a small system: the handle replays them from a hipGraph (64 steps
+    per replay) and launches the rest; 200 + 1 snapshot step must equal the oracle's 201."""
+    g = load_golden("g3_saturn_ring_500")
+    p, m = g["particles"], g["mass"]
+    sub = 201
+    _, ref = ol.simulate(p, m, 2, sub, float(g["dt"]), threads=8)
+    _, out = gpu_simulate(p, m, 2, sub, float(g["dt"]))
+    assert rel_pos_err(out[..., :3], ref[..., :3]) <= 1e-13
+    for sl in (slice(3, 6), slice(6, 9)):
+        scale = np.linalg.norm(ref[..., sl], axis=-1).max()
+        assert np.abs(out[..., sl] - ref[..., sl]).max() <= 1e-12 * scale
