@@ -44,7 +44,8 @@ struct SymArgs {
   const double* pos;   // all slabs, slab layout
   const double* mass;  // all slabs, flat
   double* R;           // [nR][3][S]  i-side sums of the own rows, per distance chunk
-  double* C;           // [D][3][S]   j-side sums of tile (I, I+d), indexed by OWN row I - row0
+  double* C;           // [Db][3][S]  j-side sums of tile (I, I+d) at row d - c_base, indexed by
+                       //             OWN row I - row0; Db = distances per batch
   int64_t S;           // slots per slab
   int nbs;             // blocks per slab = S / B
   int nb;              // blocks in all = num_shards * nbs
@@ -53,7 +54,9 @@ struct SymArgs {
   int d_lo, d_hi;      // distances this launch covers, inclusive
   int dsplit;          // chunks [d_lo, d_hi] is cut into (grid.y)
   int r_base;          // R chunk of this launch's chunk 0
-  int nR;              // R chunks the finishing kernel adds up
+  int r_first;         // first R chunk the finishing kernels add (0 = include the local phase's)
+  int nR;              // one past the last R chunk they add
+  int c_base;          // distance stored in row 0 of C for this batch
   double eps2;
 };
 
@@ -199,7 +202,7 @@ __global__ __launch_bounds__(256) void sym_tiles_kernel(const SymArgs a) {
     else tile_phases<IPT, false>(xy, zm, fJ, lane, w, xi, yi, zi, mi, ax, ay, az, eps2, c15, c1875);
 
     if (sym) {
-      double* Cd = a.C + static_cast<int64_t>(d - 1) * 3 * S + static_cast<int64_t>(il) * B;
+      double* Cd = a.C + static_cast<int64_t>(d - a.c_base) * 3 * S + static_cast<int64_t>(il) * B;
 #pragma unroll
       for (int k = 0; k < IPT; k++) {
         const int idx = k * 256 + tid;
@@ -220,9 +223,10 @@ __global__ __launch_bounds__(256) void sym_tiles_kernel(const SymArgs a) {
   }
 }
 
-// Everything this rank has computed for global slot g = (slab, off), added in a fixed order:
-// the own rows' i-side chunks R[s] (own slab only) and, for every own row I that met g's
-// block J at a distance 1 <= d = J - I (mod nb) <= D, the j-side sums C[d][I][.].
+// Everything this rank has computed IN THIS BATCH of distances for global slot
+// g = (slab, off), added in a fixed order: the own rows' i-side chunks R[r_first..nR) (own
+// slab only) and, for every own row I that met g's block J at a distance d = J - I (mod nb)
+// inside [max(d_lo,1), d_hi], the j-side sums C[d - c_base][I][.].
 template <int B>
 __device__ __forceinline__ void sum_partials(const SymArgs& sa, int slab, int64_t off, bool own_slab,
                                              double* ax, double* ay, double* az) {
@@ -231,19 +235,20 @@ __device__ __forceinline__ void sum_partials(const SymArgs& sa, int slab, int64_
   const int jl = static_cast<int>(off % B);
   double x = 0.0, y = 0.0, z = 0.0;
   if (own_slab) {
-    for (int s = 0; s < sa.nR; s++) {
+    for (int s = sa.r_first; s < sa.nR; s++) {
       const double* Rs = sa.R + static_cast<int64_t>(s) * 3 * S + off;
       x += Rs[0];
       y += Rs[S];
       z += Rs[2 * S];
     }
   }
+  const int d_min = sa.d_lo > 1 ? sa.d_lo : 1;
   for (int il = 0; il < sa.nbs; il++) {
     const int I = sa.row0 + il;
     int d = J - I;
     if (d < 0) d += sa.nb;
-    if (d < 1 || d > sa.D || (2 * d == sa.nb && I >= sa.nb / 2)) continue;
-    const double* Cd = sa.C + static_cast<int64_t>(d - 1) * 3 * S + static_cast<int64_t>(il) * B + jl;
+    if (d < d_min || d > sa.d_hi || (2 * d == sa.nb && I >= sa.nb / 2)) continue;
+    const double* Cd = sa.C + static_cast<int64_t>(d - sa.c_base) * 3 * S + static_cast<int64_t>(il) * B + jl;
     x += Cd[0];
     y += Cd[S];
     z += Cd[2 * S];
@@ -251,7 +256,7 @@ __device__ __forceinline__ void sum_partials(const SymArgs& sa, int slab, int64_
   *ax = x; *ay = y; *az = z;
 }
 
-// one slab: partial sums are complete sums -> integrate directly
+// one slab, one batch: the partial sums are the complete sums -> integrate directly
 template <int IPT>
 __global__ __launch_bounds__(256) void sym_finish_kernel(const SymArgs sa, const nbody_mi355x_step_args a) {
   const int64_t g = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
@@ -262,11 +267,11 @@ __global__ __launch_bounds__(256) void sym_finish_kernel(const SymArgs sa, const
   integrate_and_store(a, g, a.pos_cur[g], a.pos_cur[S + g], a.pos_cur[2 * S + g], ax, ay, az);
 }
 
-// several slabs (ranks): this rank's partial sums for EVERY slot, [num_shards][3][S]; the
-// caller reduce-scatters them and integrates with an acc_in step.
+// several slabs (ranks) and/or several batches: this rank's partial sums of this batch for
+// EVERY slot into out[num_shards][3][S] (first batch: stored; later batches: added).
 template <int IPT>
 __global__ __launch_bounds__(256) void sym_gather_kernel(const SymArgs sa, int own_shard, int num_shards,
-                                                         double* __restrict__ out) {
+                                                         bool first, double* __restrict__ out) {
   const int64_t S = sa.S;
   const int64_t g = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
   if (g >= S * num_shards) return;
@@ -275,15 +280,40 @@ __global__ __launch_bounds__(256) void sym_gather_kernel(const SymArgs sa, int o
   double ax, ay, az;
   sum_partials<256 * IPT>(sa, slab, off, slab == own_shard, &ax, &ay, &az);
   double* o = out + static_cast<int64_t>(slab) * 3 * S + off;
-  o[0] = ax;
-  o[S] = ay;
-  o[2 * S] = az;
+  if (first) {
+    o[0] = ax;
+    o[S] = ay;
+    o[2 * S] = az;
+  } else {
+    o[0] += ax;
+    o[S] += ay;
+    o[2 * S] += az;
+  }
+}
+
+// one slab, several batches: integrate from the accumulated sums
+__global__ __launch_bounds__(256) void sym_integrate_kernel(const double* __restrict__ acc,
+                                                            const nbody_mi355x_step_args a) {
+  const int64_t g = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (g >= a.own_count) return;
+  const int64_t S = a.shard_slots;
+  integrate_and_store(a, g, a.pos_cur[g], a.pos_cur[S + g], a.pos_cur[2 * S + g], acc[g], acc[S + g],
+                      acc[2 * S + g]);
 }
 
 struct Plan {
   int ipt, nbs, nb, D, dsplit;
-  int64_t bytes;
+  int64_t bytes;      // preferred workspace: every distance in one batch, capped (kBatchCap)
+  int64_t row_bytes;  // 3 * S doubles: one R chunk / one distance of C / the batch accumulator
 };
+
+// Above this the distances are processed in batches that reuse the C rows (the workspace
+// of one batch would otherwise grow as N^2 / block: 206 GB at N = 4M on one GPU).
+constexpr int64_t kBatchCap = int64_t{16} << 30;
+
+// rows of the workspace that are not C: R chunks (1 local + ds) and, on one slab, the
+// accumulator that batches add into
+int64_t fixed_rows(const Plan& p, int num_shards) { return 1 + p.dsplit + (num_shards == 1 ? 1 : 0); }
 
 // One candidate block size: fills *p and returns its modelled time (arbitrary units), or a
 // negative value if it does not apply.
@@ -318,8 +348,10 @@ double plan_for(const nbody_mi355x_step_args& a, int ipt, Plan* p) {
   if (ds > p->D) ds = p->D;
   if (ds < 1) ds = 1;
   p->dsplit = ds;
-  // R: 1 chunk for the local phase (d = 0) + ds chunks; C: D distances
-  p->bytes = static_cast<int64_t>(sizeof(double)) * 3 * a.shard_slots * (1 + static_cast<int64_t>(ds) + p->D);
+  p->row_bytes = static_cast<int64_t>(sizeof(double)) * 3 * a.shard_slots;
+  const int64_t full = p->row_bytes * (fixed_rows(*p, a.num_shards) + p->D);
+  const int64_t least = p->row_bytes * (fixed_rows(*p, a.num_shards) + 1);
+  p->bytes = full <= kBatchCap ? full : (least > kBatchCap ? least : kBatchCap);
   return best;
 }
 
@@ -344,34 +376,45 @@ bool make_plan(const nbody_mi355x_step_args& a, Plan* p) {
 }
 
 template <int IPT>
-hipError_t launch(SymArgs sa, const nbody_mi355x_step_args& a, hipStream_t stream) {
+hipError_t launch(SymArgs sa, const nbody_mi355x_step_args& a, hipStream_t stream, int batch, double* accum) {
   hipError_t e = hipSuccess;
-  // phase 1 = what needs the own slab only (the diagonal tiles); phase 2 = the rest;
-  // phase 0 = both in one launch
-  const int phase = a.phase;
-  if (phase == 1) {
-    sa.d_lo = 0; sa.d_hi = 0; sa.dsplit = 1; sa.r_base = 0;
-  } else if (phase == 2) {
-    sa.d_lo = 1; sa.d_hi = sa.D; sa.r_base = 1;  // dsplit as planned
-  } else {
-    sa.d_lo = 0; sa.d_hi = sa.D; sa.r_base = 1;  // chunk R[0] unused: zeroed below
+  // phase 1 = what needs the own slab only (the diagonal tiles), kept in R[0];
+  // phase 2 = the rest, then output; phase 0 = both
+  if (a.phase == 1) {
+    sa.d_lo = 0; sa.d_hi = 0; sa.dsplit = 1; sa.r_base = 0; sa.c_base = 1;
+    hipLaunchKernelGGL((sym_tiles_kernel<IPT>), dim3(sa.nbs, 1), dim3(256), 0, stream, sa);
+    return hipGetLastError();
   }
-  if (phase == 0) {
-    e = hipMemsetAsync(sa.R, 0, sizeof(double) * 3 * static_cast<size_t>(sa.S), stream);
+  const int d_first = a.phase == 2 ? 1 : 0;
+  sa.r_base = 1;
+  double* out = a.acc_out != nullptr ? a.acc_out : accum;
+  for (int lo = d_first; lo <= sa.D; lo += batch) {
+    const int hi = (lo + batch - 1 < sa.D) ? lo + batch - 1 : sa.D;
+    const bool first = lo == d_first, only = first && hi == sa.D;
+    sa.d_lo = lo;
+    sa.d_hi = hi;
+    sa.c_base = lo > 1 ? lo : 1;
+    sa.r_first = (first && a.phase == 2) ? 0 : 1;  // the local phase's chunk joins the first batch
+    hipLaunchKernelGGL((sym_tiles_kernel<IPT>), dim3(sa.nbs, sa.dsplit), dim3(256), 0, stream, sa);
+    e = hipGetLastError();
     if (e != hipSuccess) return e;
-  }
-  hipLaunchKernelGGL((sym_tiles_kernel<IPT>), dim3(sa.nbs, sa.dsplit), dim3(256), 0, stream, sa);
-  e = hipGetLastError();
-  if (e != hipSuccess || phase == 1) return e;
-  if (a.acc_out != nullptr) {
+    if (only && a.acc_out == nullptr) {
+      hipLaunchKernelGGL((sym_finish_kernel<IPT>), dim3(static_cast<unsigned>((a.own_count + 255) / 256)),
+                         dim3(256), 0, stream, sa, a);
+      return hipGetLastError();
+    }
     const int64_t total = sa.S * a.num_shards;
     hipLaunchKernelGGL((sym_gather_kernel<IPT>), dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0,
-                       stream, sa, a.own_shard, a.num_shards, a.acc_out);
-  } else {
-    hipLaunchKernelGGL((sym_finish_kernel<IPT>), dim3(static_cast<unsigned>((a.own_count + 255) / 256)),
-                       dim3(256), 0, stream, sa, a);
+                       stream, sa, a.own_shard, a.num_shards, first, out);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
   }
-  return hipGetLastError();
+  if (a.acc_out == nullptr) {
+    hipLaunchKernelGGL(sym_integrate_kernel, dim3(static_cast<unsigned>((a.own_count + 255) / 256)), dim3(256),
+                       0, stream, accum, a);
+    e = hipGetLastError();
+  }
+  return e;
 }
 
 }  // namespace
@@ -405,27 +448,35 @@ int sym_step(const nbody_mi355x_step_args& a, hipStream_t stream) {
               "(the partial sums must be reduce-scattered before integrating)", a.num_shards);
     return NBODY_MI355X_ERR_INVALID;
   }
-  if (!a.workspace || a.workspace_bytes < p.bytes) {
-    set_error("symmetric step: workspace of %lld bytes needed, %lld given", (long long)p.bytes,
-              (long long)a.workspace_bytes);
+  const int64_t fixed = fixed_rows(p, a.num_shards);
+  const int64_t rows = a.workspace ? a.workspace_bytes / p.row_bytes : 0;
+  if (rows < fixed + 1) {
+    set_error("symmetric step: workspace of at least %lld bytes needed (%lld preferred), %lld given",
+              (long long)(p.row_bytes * (fixed + 1)), (long long)p.bytes, (long long)a.workspace_bytes);
     return NBODY_MI355X_ERR_INVALID;
   }
+  int64_t batch = rows - fixed;  // distances whose j-side sums fit at once
+  if (batch > p.D) batch = p.D;
   SymArgs sa;
   sa.pos = a.pos_cur;
   sa.mass = a.mass;
   sa.R = static_cast<double*>(a.workspace);
   sa.C = sa.R + static_cast<int64_t>(1 + p.dsplit) * 3 * a.shard_slots;
+  double* accum = a.num_shards == 1 ? sa.C + batch * 3 * a.shard_slots : nullptr;
   sa.S = a.shard_slots;
   sa.nbs = p.nbs;
   sa.nb = p.nb;
   sa.row0 = a.own_shard * p.nbs;
   sa.D = p.D;
   sa.dsplit = p.dsplit;
+  sa.r_first = 1;
   sa.nR = 1 + p.dsplit;
   sa.d_lo = sa.d_hi = sa.r_base = 0;
+  sa.c_base = 1;
   sa.eps2 = a.eps2;
-  const hipError_t e = p.ipt == 1 ? launch<1>(sa, a, stream)
-                       : p.ipt == 2 ? launch<2>(sa, a, stream) : launch<4>(sa, a, stream);
+  const int b = static_cast<int>(batch);
+  const hipError_t e = p.ipt == 1 ? launch<1>(sa, a, stream, b, accum)
+                       : p.ipt == 2 ? launch<2>(sa, a, stream, b, accum) : launch<4>(sa, a, stream, b, accum);
   if (e != hipSuccess) {
     set_error("symmetric step launch: %s", hipGetErrorString(e));
     return NBODY_MI355X_ERR_LAUNCH;

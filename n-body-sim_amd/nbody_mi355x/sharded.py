@@ -127,6 +127,7 @@ class ShardedNBody:
                 if world > 1:
                     self.acc_all = torch.zeros((world, 3, S), dtype=torch.float64, device=dev)
         self.sym_variant = variant if variant in SYM_VARIANTS else VARIANT_SYM
+        self._send = None
         self.cur = 0
         self._fresh = True  # every slab of pos[cur] is current (true right after upload)
 
@@ -191,8 +192,13 @@ class ShardedNBody:
         flat = buf.view(-1)
         own = flat[self.rank * 3 * self.S:(self.rank + 1) * 3 * self.S]
         if dist.get_backend(self.group) == "nccl" or buf.device.type == "cpu":
-            # in place: the input is this rank's slab inside the output
-            return dist.all_gather_into_tensor(flat, own, group=self.group, async_op=async_op)
+            # ONE collective: every rank's slab (3*S doubles) into its place in the slab
+            # layout.  The send side is a private copy of the own slab (a 3*S-double device
+            # copy, microseconds) so that input and output never alias.
+            if self._send is None:
+                self._send = torch.empty_like(own)
+            self._send.copy_(own)
+            return dist.all_gather_into_tensor(flat, self._send, group=self.group, async_op=async_op)
         # gloo with device tensors (rehearsals): staged via the host, out of place
         mine = own.cpu()
         parts = [torch.empty_like(mine) for _ in range(self.world)]

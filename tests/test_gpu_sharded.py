@@ -192,3 +192,47 @@ def test_two_real_ranks_end_to_end(n, expect_sym):
     assert rel_pos_err(snap[:, :3], out[0, :, :3]) <= 1e-13
     num = np.linalg.norm(snap[:, 6:9] - out[0, :, 6:9], axis=1)
     assert (num / np.linalg.norm(out[0, :, 6:9], axis=1)).max() <= 1e-12
+
+
+@pytest.mark.parametrize("world,n,rows", [(1, 20000, 8), (1, 20000, 5), (2, 30000, 36), (1, 5000, 5)])
+def test_symmetric_distance_batching(world, n, rows):
+    """A workspace too small for every distance at once: the symmetric kernels work through
+    the distances in batches that reuse it.  Same answer as with the full workspace."""
+    p, m = nb.ic_plummer(n, 17)
+    sims = [ShardedNBody(p, m, 1e-3, rank=r, world=world, device="cuda") for r in range(world)]
+    for s in sims:
+        assert s.workspace is not None
+        row = 3 * s.S
+        assert s.workspace.numel() > rows * row          # the preferred size is larger
+        s.workspace = torch.empty(rows * row, dtype=torch.float64, device="cuda")
+    for s in sims:
+        common = dict(pos_cur=s.pos[0], pos_next=s.pos[1], mass=s.mass, vel=s.vel, S=s.S, world=world,
+                      rank=s.rank, count=s.count, dt=s.dt, G=s.G, eps2=0.0)
+        if world == 1:
+            s.backend.step(acc_in=None, acc_out=None, snapshot=s.snap, ranges=((0, n), (0, 0)),
+                           workspace=s.workspace, **common)
+        else:
+            s._common = common
+            s._sym_forces(s.pos[0], common)
+    if world > 1:
+        total = sum(s.acc_all for s in sims)
+        for s in sims:
+            s.acc.copy_(total[s.rank])
+            s._integrate(s._common, s.snap)
+    torch.cuda.synchronize()
+    _, out = ol.simulate(p, m, 1, 1, 1e-3, threads=16)
+    snap = np.concatenate([s.own_snapshot() for s in sims])
+    num = np.linalg.norm(snap[:, 6:9] - out[0, :, 6:9], axis=1)
+    assert (num / np.linalg.norm(out[0, :, 6:9], axis=1)).max() <= 1e-12
+    assert rel_pos_err(snap[:, :3], out[0, :, :3]) <= 1e-15
+
+
+def test_symmetric_workspace_too_small_is_an_error():
+    p, m = nb.ic_plummer(20000, 17)
+    s = ShardedNBody(p, m, 1e-3, device="cuda")
+    s.workspace = torch.empty(3 * s.S * 2, dtype=torch.float64, device="cuda")
+    with pytest.raises(nb.NBodyError) as e:
+        s.backend.step(pos_cur=s.pos[0], pos_next=s.pos[1], mass=s.mass, vel=s.vel, S=s.S, world=1, rank=0,
+                       count=s.count, dt=s.dt, G=s.G, eps2=0.0, acc_in=None, acc_out=None, snapshot=None,
+                       ranges=((0, 20000), (0, 0)), workspace=s.workspace, variant=nb.VARIANT_SYM)
+    assert e.value.code == nb.ERR_INVALID and "workspace" in str(e.value)
