@@ -31,6 +31,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdlib>
 
 #include "nbody_device.hpp"
 #include "nbody_internal.h"
@@ -53,6 +54,7 @@ struct SymArgs {
   int D;               // largest distance = nb / 2
   int d_lo, d_hi;      // distances this launch covers, inclusive
   int dsplit;          // chunks [d_lo, d_hi] is cut into (grid.y)
+  int jsplit;          // parts a tile's j groups are cut into (grid.z): 1, 2 or 4, <= IPT
   int r_base;          // R chunk of this launch's chunk 0
   int r_first;         // first R chunk the finishing kernels add (0 = include the local phase's)
   int nR;              // one past the last R chunk they add
@@ -74,17 +76,17 @@ __device__ __forceinline__ double rotate_from_next_lane(double v) {
   return __hiloint2double(hi, lo);
 }
 
-// All 4*IPT j groups of the staged tile against this wave's 64*IPT bodies.  SYM = false is
+// The workgroup's j groups of the staged tile against this wave's 64*IPT bodies.  SYM = false is
 // the diagonal tile (a block against itself): i side only, no barriers needed.
 template <int IPT, bool SYM>
 __device__ __forceinline__ void tile_phases(const D2* xy, const D2* zm, double (*fJ)[256 * IPT], int lane,
-                                            int w, const double (&xi)[IPT], const double (&yi)[IPT],
+                                            int w, int g0, int ng, const double (&xi)[IPT], const double (&yi)[IPT],
                                             const double (&zi)[IPT], const double (&mi)[IPT],
                                             double (&ax)[IPT], double (&ay)[IPT], double (&az)[IPT],
                                             double eps2, double c15, double c1875) {
-  constexpr int NG = 4 * IPT;
-  for (int ph = 0; ph < NG; ph++) {
-    const int grp = (ph + IPT * w) % NG;  // the 4 waves sit on 4 different groups
+  // this workgroup's share of the tile: groups g0 .. g0+ng-1 (ng a multiple of 4)
+  for (int ph = 0; ph < ng; ph++) {
+    const int grp = g0 + (ph + (ng >> 2) * w) % ng;  // the 4 waves sit on 4 different groups
     const int base = grp * 64;
     double fx = 0.0, fy = 0.0, fz = 0.0;
     int rot = lane;
@@ -150,6 +152,9 @@ __global__ __launch_bounds__(256) void sym_tiles_kernel(const SymArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int il = blockIdx.x, s = blockIdx.y;  // own row (local index), distance chunk
+  const int ng = (4 * IPT) / a.jsplit;        // j groups of a tile this workgroup takes ...
+  const int g0 = blockIdx.z * ng;             // ... starting here (64 bodies per group)
+  const int j_lo = g0 * 64, j_n = ng * 64;    // = bodies [j_lo, j_lo + j_n) of the J block
   const int I = a.row0 + il;
   const int64_t S = a.S;
   const double eps2 = (a.eps2 > 0.0) ? a.eps2 : kTinyR2;
@@ -186,9 +191,8 @@ __global__ __launch_bounds__(256) void sym_tiles_kernel(const SymArgs a) {
     {
       const double *px, *pm;
       block_base<B>(a, J, &px, &pm);
-#pragma unroll
-      for (int k = 0; k < IPT; k++) {
-        const int idx = k * 256 + tid;
+      for (int o = tid; o < j_n; o += 256) {  // j_n is a multiple of 256 (jsplit <= IPT)
+        const int idx = j_lo + o;
         xy[idx] = D2{px[idx], px[S + idx]};
         zm[idx] = D2{px[2 * S + idx], pm[idx]};
         fJ[0][idx] = 0.0;
@@ -198,14 +202,13 @@ __global__ __launch_bounds__(256) void sym_tiles_kernel(const SymArgs a) {
     }
     __syncthreads();
 
-    if (sym) tile_phases<IPT, true>(xy, zm, fJ, lane, w, xi, yi, zi, mi, ax, ay, az, eps2, c15, c1875);
-    else tile_phases<IPT, false>(xy, zm, fJ, lane, w, xi, yi, zi, mi, ax, ay, az, eps2, c15, c1875);
+    if (sym) tile_phases<IPT, true>(xy, zm, fJ, lane, w, g0, ng, xi, yi, zi, mi, ax, ay, az, eps2, c15, c1875);
+    else tile_phases<IPT, false>(xy, zm, fJ, lane, w, g0, ng, xi, yi, zi, mi, ax, ay, az, eps2, c15, c1875);
 
     if (sym) {
       double* Cd = a.C + static_cast<int64_t>(d - a.c_base) * 3 * S + static_cast<int64_t>(il) * B;
-#pragma unroll
-      for (int k = 0; k < IPT; k++) {
-        const int idx = k * 256 + tid;
+      for (int o = tid; o < j_n; o += 256) {
+        const int idx = j_lo + o;
         Cd[idx] = fJ[0][idx];
         Cd[S + idx] = fJ[1][idx];
         Cd[2 * S + idx] = fJ[2][idx];
@@ -213,7 +216,8 @@ __global__ __launch_bounds__(256) void sym_tiles_kernel(const SymArgs a) {
     }
   }
 
-  double* Rs = a.R + static_cast<int64_t>(a.r_base + s) * 3 * S + static_cast<int64_t>(il) * B;
+  double* Rs = a.R + static_cast<int64_t>(a.r_base + s * a.jsplit + static_cast<int>(blockIdx.z)) * 3 * S +
+               static_cast<int64_t>(il) * B;
 #pragma unroll
   for (int k = 0; k < IPT; k++) {
     const int idx = k * 256 + tid;
@@ -302,7 +306,7 @@ __global__ __launch_bounds__(256) void sym_integrate_kernel(const double* __rest
 }
 
 struct Plan {
-  int ipt, nbs, nb, D, dsplit;
+  int ipt, nbs, nb, D, dsplit, jsplit;
   int64_t bytes;      // preferred workspace: every distance in one batch, capped (kBatchCap)
   int64_t row_bytes;  // 3 * S doubles: one R chunk / one distance of C / the batch accumulator
 };
@@ -313,7 +317,9 @@ constexpr int64_t kBatchCap = int64_t{16} << 30;
 
 // rows of the workspace that are not C: R chunks (1 local + ds) and, on one slab, the
 // accumulator that batches add into
-int64_t fixed_rows(const Plan& p, int num_shards) { return 1 + p.dsplit + (num_shards == 1 ? 1 : 0); }
+int64_t fixed_rows(const Plan& p, int num_shards) {
+  return 1 + static_cast<int64_t>(p.dsplit) * p.jsplit + (num_shards == 1 ? 1 : 0);
+}
 
 // One candidate block size: fills *p and returns its modelled time (arbitrary units), or a
 // negative value if it does not apply.
@@ -326,28 +332,32 @@ double plan_for(const nbody_mi355x_step_args& a, int ipt, Plan* p) {
   if (nb < 2 || nb > (1 << 24)) return -1.0;
   p->nb = static_cast<int>(nb);
   p->D = p->nb / 2;
-  // Every row has D+1 equal tiles, cut into ds chunks -> nbs*ds workgroups per launch, up to
-  // `per_cu` of them resident on a CU (LDS / VGPR budget of the kernel build), each getting
-  // 1/k of the CU when k share it.  Critical path = rounds * tiles-per-workgroup * k * tile
-  // cost; a lone workgroup (k = 1, one wave per SIMD) cannot keep the FP64 pipe full.
+  // Work items: every row has D+1 equal tiles; a row is cut into ds distance chunks and a
+  // tile into jsplit parts -> nbs*ds*jsplit workgroups, dispatched dynamically by the
+  // hardware as others retire.  Measured on MI355X (N = 65 536 .. 262 144): throughput
+  // rises with the number of chunks up to ~16-32 and is flat beyond, and what is left is
+  // the tail of one work item; so: up to 32 chunks, and tiles split until there are ~32
+  // items per CU.  Model time = work / 256 CUs + one item at full CU residency.
   const int per_cu = ipt == 4 ? 2 : (ipt == 2 ? 4 : 8);
   const double pair_cost = ipt == 4 ? 1.00 : (ipt == 2 ? 1.06 : 1.17);  // DPP + addressing per pair
   const int nd = p->D + 1;
-  int ds = 1;
-  double best = -1.0;
-  for (int c = 1; c <= nd && c <= 64; c++) {
-    const int64_t wgs = static_cast<int64_t>(p->nbs) * c;
-    const int64_t rounds = (wgs + 256 * per_cu - 1) / (256 * per_cu);
-    int64_t k = (wgs + 255) / 256;
-    if (k > per_cu) k = per_cu;
-    const double lone = k == 1 ? 1.5 : 1.0;
-    const double t = static_cast<double>(rounds) * ((nd + c - 1) / c) * static_cast<double>(k) * lone *
-                     static_cast<double>(B) * static_cast<double>(B) * pair_cost;
-    if (best < 0.0 || t < best) { best = t; ds = c; }
+  int ds = nd < 32 ? nd : 32;
+  if (const char* env = getenv("NBODY_MI355X_SYM_DSPLIT")) {  // tuning experiments only
+    const int v = atoi(env);
+    if (v > 0) ds = v;
   }
   if (ds > p->D) ds = p->D;
   if (ds < 1) ds = 1;
   p->dsplit = ds;
+  int js = 1;
+  while (js < ipt && static_cast<int64_t>(p->nbs) * nd * js < 32 * 256) js *= 2;
+  if (const char* env = getenv("NBODY_MI355X_SYM_JSPLIT")) {  // tuning experiments only
+    const int v = atoi(env);
+    if ((v == 1 || v == 2 || v == 4) && v <= ipt) js = v;
+  }
+  p->jsplit = js;
+  const double tile = static_cast<double>(B) * static_cast<double>(B) * pair_cost;
+  const double best = static_cast<double>(p->nbs) * nd * tile / 256.0 + tile / js * per_cu;
   p->row_bytes = static_cast<int64_t>(sizeof(double)) * 3 * a.shard_slots;
   const int64_t full = p->row_bytes * (fixed_rows(*p, a.num_shards) + p->D);
   const int64_t least = p->row_bytes * (fixed_rows(*p, a.num_shards) + 1);
@@ -381,21 +391,23 @@ hipError_t launch(SymArgs sa, const nbody_mi355x_step_args& a, hipStream_t strea
   // phase 1 = what needs the own slab only (the diagonal tiles), kept in R[0];
   // phase 2 = the rest, then output; phase 0 = both
   if (a.phase == 1) {
-    sa.d_lo = 0; sa.d_hi = 0; sa.dsplit = 1; sa.r_base = 0; sa.c_base = 1;
-    hipLaunchKernelGGL((sym_tiles_kernel<IPT>), dim3(sa.nbs, 1), dim3(256), 0, stream, sa);
+    sa.d_lo = 0; sa.d_hi = 0; sa.dsplit = 1; sa.jsplit = 1; sa.r_base = 0; sa.c_base = 1;
+    hipLaunchKernelGGL((sym_tiles_kernel<IPT>), dim3(sa.nbs, 1, 1), dim3(256), 0, stream, sa);
     return hipGetLastError();
   }
   const int d_first = a.phase == 2 ? 1 : 0;
   sa.r_base = 1;
   double* out = a.acc_out != nullptr ? a.acc_out : accum;
-  for (int lo = d_first; lo <= sa.D; lo += batch) {
-    const int hi = (lo + batch - 1 < sa.D) ? lo + batch - 1 : sa.D;
+  for (int lo = d_first, hi; lo <= sa.D; lo = hi + 1) {
+    // `batch` rows of C hold the distances max(lo,1) .. hi (d = 0 needs none)
+    hi = (lo > 1 ? lo : 1) + batch - 1;
+    if (hi > sa.D) hi = sa.D;
     const bool first = lo == d_first, only = first && hi == sa.D;
     sa.d_lo = lo;
     sa.d_hi = hi;
     sa.c_base = lo > 1 ? lo : 1;
     sa.r_first = (first && a.phase == 2) ? 0 : 1;  // the local phase's chunk joins the first batch
-    hipLaunchKernelGGL((sym_tiles_kernel<IPT>), dim3(sa.nbs, sa.dsplit), dim3(256), 0, stream, sa);
+    hipLaunchKernelGGL((sym_tiles_kernel<IPT>), dim3(sa.nbs, sa.dsplit, sa.jsplit), dim3(256), 0, stream, sa);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (only && a.acc_out == nullptr) {
@@ -461,7 +473,7 @@ int sym_step(const nbody_mi355x_step_args& a, hipStream_t stream) {
   sa.pos = a.pos_cur;
   sa.mass = a.mass;
   sa.R = static_cast<double*>(a.workspace);
-  sa.C = sa.R + static_cast<int64_t>(1 + p.dsplit) * 3 * a.shard_slots;
+  sa.C = sa.R + static_cast<int64_t>(1 + p.dsplit * p.jsplit) * 3 * a.shard_slots;
   double* accum = a.num_shards == 1 ? sa.C + batch * 3 * a.shard_slots : nullptr;
   sa.S = a.shard_slots;
   sa.nbs = p.nbs;
@@ -469,8 +481,9 @@ int sym_step(const nbody_mi355x_step_args& a, hipStream_t stream) {
   sa.row0 = a.own_shard * p.nbs;
   sa.D = p.D;
   sa.dsplit = p.dsplit;
+  sa.jsplit = p.jsplit;
   sa.r_first = 1;
-  sa.nR = 1 + p.dsplit;
+  sa.nR = 1 + p.dsplit * p.jsplit;
   sa.d_lo = sa.d_hi = sa.r_base = 0;
   sa.c_base = 1;
   sa.eps2 = a.eps2;

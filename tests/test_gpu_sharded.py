@@ -194,8 +194,8 @@ def test_two_real_ranks_end_to_end(n, expect_sym):
     assert (num / np.linalg.norm(out[0, :, 6:9], axis=1)).max() <= 1e-12
 
 
-@pytest.mark.parametrize("world,n,rows", [(1, 20000, 8), (1, 20000, 5), (2, 30000, 36), (1, 5000, 5)])
-def test_symmetric_distance_batching(world, n, rows):
+@pytest.mark.parametrize("world,n,drop", [(1, 20000, 1), (1, 20000, 7), (2, 30000, 5), (1, 5000, 3)])
+def test_symmetric_distance_batching(world, n, drop):
     """A workspace too small for every distance at once: the symmetric kernels work through
     the distances in batches that reuse it.  Same answer as with the full workspace."""
     p, m = nb.ic_plummer(n, 17)
@@ -203,7 +203,7 @@ def test_symmetric_distance_batching(world, n, rows):
     for s in sims:
         assert s.workspace is not None
         row = 3 * s.S
-        assert s.workspace.numel() > rows * row          # the preferred size is larger
+        rows = s.workspace.numel() // row - drop         # the preferred size holds every distance
         s.workspace = torch.empty(rows * row, dtype=torch.float64, device="cuda")
     for s in sims:
         common = dict(pos_cur=s.pos[0], pos_next=s.pos[1], mass=s.mass, vel=s.vel, S=s.S, world=world,
