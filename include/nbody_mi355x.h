@@ -49,6 +49,15 @@ typedef enum {
 #define NBODY_MI355X_FP64 0 /* everything in double (parity path)                */
 #define NBODY_MI355X_FP32 1 /* separations in double, r^-3 and sums in float      */
 
+/* Time integrator fused into the step's epilogue.
+ * EULER: the reference's forward Euler, v' = v + dt a, r' = r + dt v (OLD v)
+ *        (ref: particle_simulation.h:288-300) -- the parity path.
+ * KICK_DRIFT: r' = r + dt v' (NEW v): the symplectic (semi-implicit) Euler step, i.e.
+ *        leapfrog with velocities read half a step late; same force kernel, same
+ *        cost, bounded energy error.  Not in the reference. */
+#define NBODY_MI355X_EULER 0
+#define NBODY_MI355X_KICK_DRIFT 1
+
 /* Tile width of the j loop; shard_slots must be a multiple of it. */
 #define NBODY_MI355X_TILE 256
 
@@ -110,7 +119,8 @@ typedef struct {
                              sums for EVERY slot, to be reduce-scattered and
                              integrated by a one-sided step with acc_in and
                              empty j ranges.                                   */
-  int32_t reserved;
+  int32_t integrator;     /* NBODY_MI355X_EULER (the reference's, default) or
+                             NBODY_MI355X_KICK_DRIFT                           */
 } nbody_mi355x_step_args;
 
 #define NBODY_MI355X_VARIANT_SYM  10 /* pair-symmetric, block size chosen by the library */
@@ -164,6 +174,8 @@ typedef struct {
   int32_t host_is_float; /* 0: host records are double (ParticleSimulation<double,W>),
                             1: float (ParticleSimulation<float,W>)             */
   int32_t variant;       /* as in nbody_mi355x_step_args                       */
+  int32_t integrator;    /* NBODY_MI355X_EULER (default) / NBODY_MI355X_KICK_DRIFT */
+  int32_t reserved;
 } nbody_mi355x_config;
 
 /* ref: AllocateDeviceMemory, particle_simulation_GPU.cu:13-35 (4 cudaMalloc). */

@@ -85,9 +85,11 @@ __device__ __forceinline__ void integrate_and_store(const nbody_mi355x_step_args
   const double nvx = __builtin_fma(a.dt * axd, a.G, vx);
   const double nvy = __builtin_fma(a.dt * ayd, a.G, vy);
   const double nvz = __builtin_fma(a.dt * azd, a.G, vz);
-  const double nx = __builtin_fma(a.dt, vx, xi);
-  const double ny = __builtin_fma(a.dt, vy, yi);
-  const double nz = __builtin_fma(a.dt, vz, zi);
+  // the reference drifts with the OLD velocity; KICK_DRIFT with the one just kicked
+  const bool kd = a.integrator == NBODY_MI355X_KICK_DRIFT;
+  const double nx = __builtin_fma(a.dt, kd ? nvx : vx, xi);
+  const double ny = __builtin_fma(a.dt, kd ? nvy : vy, yi);
+  const double nz = __builtin_fma(a.dt, kd ? nvz : vz, zi);
   a.vel[li] = nvx;
   a.vel[S + li] = nvy;
   a.vel[2 * S + li] = nvz;

@@ -419,6 +419,10 @@ static int check_step_args(const nbody_mi355x_step_args* a) {
     set_error("step: unknown precision %d", a->precision);
     return NBODY_MI355X_ERR_INVALID;
   }
+  if (a->integrator != NBODY_MI355X_EULER && a->integrator != NBODY_MI355X_KICK_DRIFT) {
+    set_error("step: unknown integrator %d", a->integrator);
+    return NBODY_MI355X_ERR_INVALID;
+  }
   return NBODY_MI355X_OK;
 }
 

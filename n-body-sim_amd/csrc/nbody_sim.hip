@@ -93,6 +93,10 @@ extern "C" int nbody_mi355x_create(const nbody_mi355x_config* cfg, nbody_mi355x_
     set_error("create: unknown precision %d", cfg->precision);
     return NBODY_MI355X_ERR_INVALID;
   }
+  if (cfg->integrator != NBODY_MI355X_EULER && cfg->integrator != NBODY_MI355X_KICK_DRIFT) {
+    set_error("create: unknown integrator %d", cfg->integrator);
+    return NBODY_MI355X_ERR_INVALID;
+  }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
     (void)hipGetLastError();
@@ -213,6 +217,7 @@ extern "C" int nbody_mi355x_run(nbody_mi355x_sim* s, int64_t substeps, void* sna
   a.eps2 = s->cfg.eps2;
   a.precision = s->cfg.precision;
   a.variant = s->cfg.variant;
+  a.integrator = s->cfg.integrator;
   a.workspace = s->workspace;
   a.workspace_bytes = s->workspace_bytes;
   HIP_TRY(hipEventRecord(s->ev0, s->stream), NBODY_MI355X_ERR_LAUNCH, "event record");

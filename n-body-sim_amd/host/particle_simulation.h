@@ -7,7 +7,7 @@
 // compiles against this header unchanged; the one new member is
 //
 //     std::string SimulateMI355X(int device = 0, bool fp32_forces = false,
-//                                float_t softening_squared = 0);
+//                                float_t softening_squared = 0, bool kick_drift = false);
 //
 // the sibling of the reference's SimulateGPU(int blocksize) (ref: particle_simulation.h:559,
 // particle_simulation_GPU.cu:277-303).  It hands the particle records to
@@ -233,7 +233,10 @@ class ParticleSimulation {
   // a = 0, t = 0; out_put_data_[k] = state after big step k with a = G*sum, m, and
   // t = stepsize * substeps * k (ref: .cu:239-266); execution_time_ per big step;
   // progress print per big step; a "Device execution time" line; a status string.
-  std::string SimulateMI355X(int device = 0, bool fp32_forces = false, float_t softening_squared = 0) {
+  // kick_drift = true swaps the reference's forward Euler for the symplectic kick-drift
+  // step (same cost); the default reproduces the reference.
+  std::string SimulateMI355X(int device = 0, bool fp32_forces = false, float_t softening_squared = 0,
+                             bool kick_drift = false) {
     IntervallTimer device_execution_timer;
     nbody_mi355x_config cfg{};
     cfg.num_particles = num_particles_;
@@ -243,6 +246,7 @@ class ParticleSimulation {
     cfg.precision = fp32_forces ? NBODY_MI355X_FP32 : NBODY_MI355X_FP64;
     cfg.device = device;
     cfg.host_is_float = std::is_same<float_t, float>::value ? 1 : 0;
+    cfg.integrator = kick_drift ? NBODY_MI355X_KICK_DRIFT : NBODY_MI355X_EULER;
     nbody_mi355x_sim* sim = nullptr;
     int rc = nbody_mi355x_create(&cfg, &sim);
     if (rc != NBODY_MI355X_OK) return Failure(rc, nullptr);

@@ -24,6 +24,7 @@ LIB_PATH = ROOT / "lib" / "libnbody_mi355x.so"
 TILE = 256
 G_REFERENCE = 6.7430e-11  # reference: particle_simulation.h:713
 FP64, FP32 = 0, 1
+EULER, KICK_DRIFT = 0, 1
 
 OK = 0
 ERR_INVALID, ERR_ALLOC, ERR_H2D, ERR_D2H, ERR_FREE, ERR_LAUNCH, ERR_NO_DEVICE = range(-1, -8, -1)
@@ -47,7 +48,7 @@ class StepArgs(C.Structure):
         ("dt", C.c_double), ("G", C.c_double), ("eps2", C.c_double),
         ("precision", C.c_int32), ("variant", C.c_int32),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
-        ("phase", C.c_int32), ("reserved", C.c_int32),
+        ("phase", C.c_int32), ("integrator", C.c_int32),
     ]
 
 
@@ -60,6 +61,7 @@ class Config(C.Structure):
         ("num_particles", C.c_int64), ("stepsize", C.c_double), ("G", C.c_double),
         ("eps2", C.c_double), ("precision", C.c_int32), ("device", C.c_int32),
         ("host_is_float", C.c_int32), ("variant", C.c_int32),
+        ("integrator", C.c_int32), ("reserved", C.c_int32),
     ]
 
 
@@ -158,10 +160,10 @@ class Simulation:
 
     def __init__(self, num_particles: int, stepsize: float, *, G: float = G_REFERENCE,
                  eps2: float = 0.0, precision: int = FP64, device: int = 0,
-                 host_is_float: bool = False, variant: int = 0):
+                 host_is_float: bool = False, variant: int = 0, integrator: int = EULER):
         self.n = int(num_particles)
         self.host_dtype = np.float32 if host_is_float else np.float64
-        cfg = Config(self.n, stepsize, G, eps2, precision, device, int(host_is_float), variant)
+        cfg = Config(self.n, stepsize, G, eps2, precision, device, int(host_is_float), variant, integrator, 0)
         h = C.c_void_p()
         check(lib().nbody_mi355x_create(C.byref(cfg), C.byref(h)))
         self._h = h

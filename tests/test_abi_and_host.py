@@ -28,7 +28,7 @@ def test_struct_sizes_match_header_layout():
     import ctypes as C
     # 7 pointers + int64 + 2 int32 + 5 int64 + 3 double + 2 int32 + pointer + int64 + 2 int32
     assert C.sizeof(nb.StepArgs) == 7 * 8 + 8 + 8 + 5 * 8 + 3 * 8 + 8 + 16 + 8
-    assert C.sizeof(nb.Config) == 8 + 3 * 8 + 4 * 4
+    assert C.sizeof(nb.Config) == 8 + 3 * 8 + 6 * 4
 
 
 def test_invalid_arguments_fail_loudly_without_gpu():
@@ -41,7 +41,7 @@ def test_invalid_arguments_fail_loudly_without_gpu():
     a.shard_slots = 100  # not a multiple of the tile
     assert L.nbody_mi355x_step_f64(C.byref(a), None) == nb.ERR_INVALID
     assert "multiple of 256" in nb.last_error()
-    cfg = nb.Config(0, 0.1, 0, 0, 0, 0, 0, 0)
+    cfg = nb.Config(0, 0.1, 0, 0, 0, 0, 0, 0, 0, 0)
     h = C.c_void_p()
     assert L.nbody_mi355x_create(C.byref(cfg), C.byref(h)) == nb.ERR_INVALID
     with pytest.raises(nb.NBodyError):

@@ -271,3 +271,24 @@ def test_graph_replayed_substeps_match_oracle():
     for sl in (slice(3, 6), slice(6, 9)):
         scale = np.linalg.norm(ref[..., sl], axis=-1).max()
         assert np.abs(out[..., sl] - ref[..., sl]).max() <= 1e-12 * scale
+
+
+def test_kick_drift_integrator_option():
+    """The optional symplectic step (not in the reference): same forces, r' = r + dt v'.
+    One step must equal the formula; over an earth-moon month its energy error stays
+    bounded while forward Euler's grows."""
+    g = load_golden("g1_earth_moon")
+    p, m = g["particles"], g["mass"]
+    _, e1 = gpu_simulate(p, m, 1, 1, 0.1)
+    _, k1 = gpu_simulate(p, m, 1, 1, 0.1, integrator=nb.KICK_DRIFT)
+    assert np.array_equal(e1[0, :, 3:9], k1[0, :, 3:9])                     # same kick, same forces
+    np.testing.assert_allclose(k1[0, :, :3], p[:, :3] + 0.1 * k1[0, :, 3:6], rtol=1e-15, atol=1e-9)
+    dt, sub = 600.0, 4000                                                   # ~28 days, coarse steps
+    e0 = sum(ol.energy(p, m))
+    _, eu = gpu_simulate(p, m, 1, sub, dt)
+    _, kd = gpu_simulate(p, m, 1, sub, dt, integrator=nb.KICK_DRIFT)
+    drift_eu = abs(sum(ol.energy(eu[0], m)) - e0) / abs(e0)
+    drift_kd = abs(sum(ol.energy(kd[0], m)) - e0) / abs(e0)
+    assert drift_kd < 1e-4 and drift_kd < drift_eu / 10
+    with pytest.raises(nb.NBodyError):
+        nb.Simulation(2, 0.1, integrator=7)
