@@ -47,7 +47,9 @@ typedef enum {
 
 /* Arithmetic of the force accumulation. */
 #define NBODY_MI355X_FP64 0 /* everything in double (parity path)                */
-#define NBODY_MI355X_FP32 1 /* separations in double, r^-3 and sums in float      */
+#define NBODY_MI355X_FP32 1 /* forces in float: r^2, r^-3 and the running sums (and,
+                               in the pair-symmetric kernels, the separations);
+                               state, integration and snapshots stay double       */
 
 /* Time integrator fused into the step's epilogue.
  * EULER: the reference's forward Euler, v' = v + dt a, r' = r + dt v (OLD v)

@@ -434,7 +434,7 @@ extern "C" int nbody_mi355x_step_f64(const nbody_mi355x_step_args* args, void* s
   if (args->variant >= NBODY_MI355X_VARIANT_SYM && args->variant <= NBODY_MI355X_VARIANT_SYM4 &&
       args->variant != 13)
     return nbody_internal::sym_step(*args, s);
-  if (args->variant == 0 && args->workspace != nullptr && args->precision == NBODY_MI355X_FP64 &&
+  if (args->variant == 0 && args->workspace != nullptr &&
       args->acc_in == nullptr && args->acc_out == nullptr && args->own_count >= kSymMinBodies &&
       args->j0_begin == 0 && args->j1_begin == args->j1_end &&
       args->j0_end >= args->own_count) {

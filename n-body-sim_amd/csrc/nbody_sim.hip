@@ -133,7 +133,7 @@ extern "C" int nbody_mi355x_create(const nbody_mi355x_config* cfg, nbody_mi355x_
   }
   // Workspace of the symmetric kernels: taken only if it fits comfortably (it grows as
   // N^2 / 1024); without it the one-sided kernel runs, same results to rounding.
-  if (cfg->precision == NBODY_MI355X_FP64) {
+  {
     nbody_mi355x_step_args probe;
     memset(&probe, 0, sizeof probe);
     probe.shard_slots = s->slots;

@@ -62,8 +62,10 @@ struct SymArgs {
   double eps2;
 };
 
-struct alignas(16) D2 {
-  double a, b;
+// a pair of coordinates as staged in LDS: {x,y} and {z,m}, in the arithmetic type
+template <typename T>
+struct alignas(2 * sizeof(T)) P2 {
+  T a, b;
 };
 
 __device__ __forceinline__ double rotate_from_next_lane(double v) {
@@ -75,48 +77,78 @@ __device__ __forceinline__ double rotate_from_next_lane(double v) {
   hi = __builtin_amdgcn_update_dpp(hi, hi, 0x134, 0xf, 0xf, false);
   return __hiloint2double(hi, lo);
 }
+__device__ __forceinline__ float rotate_from_next_lane(float v) {
+  int b = __float_as_int(v);
+  b = __builtin_amdgcn_update_dpp(b, b, 0x134, 0xf, 0xf, false);
+  return __int_as_float(b);
+}
+
+__device__ __forceinline__ double fma_t(double a, double b, double c) { return __builtin_fma(a, b, c); }
+__device__ __forceinline__ float fma_t(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
+// The two weights of one pair from its separation: si = m_j r^-3 (applied to body i) and
+// sj = m_i r^-3 (applied to body j; only computed when WANT_J).
+// double: rsq seed + folded series, r^2 chain seeded with 2^-600 or eps2 (nbody_device.hpp).
+// float (the FP32 variant): v_rsq_f32 is good to an ulp; r^2 == 0 is an explicit select
+// because 2^-600 does not exist in float; and the mass is multiplied in BEFORE the cube is
+// completed, (m y0) (y0 y0), so that r^-3 alone never underflows (r = 1e13 m: 1e-39).
+template <bool WANT_J>
+__device__ __forceinline__ void pair_weights(double dx, double dy, double dz, double mj, double mi, double eps2,
+                                             double c15, double c1875, double* si, double* sj) {
+  const double r2 = __builtin_fma(dz, dz, __builtin_fma(dy, dy, __builtin_fma(dx, dx, eps2)));
+  const double y0 = __builtin_amdgcn_rsq(r2);
+  const double u = y0 * y0;
+  const double e = __builtin_fma(-r2, u, 1.0);
+  const double w0 = y0 * u;
+  const double p = __builtin_fma(e, c1875, c15);
+  const double we = w0 * e;
+  const double s0 = __builtin_fma(we, p, w0);  // r^-3
+  *si = s0 * mj;
+  if (WANT_J) *sj = s0 * mi;
+}
+template <bool WANT_J>
+__device__ __forceinline__ void pair_weights(float dx, float dy, float dz, float mj, float mi, float eps2,
+                                             float, float, float* si, float* sj) {
+  const float r2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, __builtin_fmaf(dx, dx, eps2)));
+  const float y = __builtin_amdgcn_rsqf(r2);
+  const float y0 = (r2 > 0.0f) ? y : 0.0f;
+  const float y2 = y0 * y0;
+  *si = (mj * y0) * y2;
+  if (WANT_J) *sj = (mi * y0) * y2;
+}
 
 // The workgroup's j groups of the staged tile against this wave's 64*IPT bodies.  SYM = false is
 // the diagonal tile (a block against itself): i side only, no barriers needed.
-template <int IPT, bool SYM>
-__device__ __forceinline__ void tile_phases(const D2* xy, const D2* zm, double (*fJ)[256 * IPT], int lane,
-                                            int w, int g0, int ng, const double (&xi)[IPT], const double (&yi)[IPT],
-                                            const double (&zi)[IPT], const double (&mi)[IPT],
-                                            double (&ax)[IPT], double (&ay)[IPT], double (&az)[IPT],
-                                            double eps2, double c15, double c1875) {
+template <int IPT, bool SYM, typename T>
+__device__ __forceinline__ void tile_phases(const P2<T>* xy, const P2<T>* zm, T (*fJ)[256 * IPT], int lane,
+                                            int w, int g0, int ng, const T (&xi)[IPT], const T (&yi)[IPT],
+                                            const T (&zi)[IPT], const T (&mi)[IPT], T (&ax)[IPT],
+                                            T (&ay)[IPT], T (&az)[IPT], T eps2, T c15, T c1875) {
   // this workgroup's share of the tile: groups g0 .. g0+ng-1 (ng a multiple of 4)
   for (int ph = 0; ph < ng; ph++) {
     const int grp = g0 + (ph + (ng >> 2) * w) % ng;  // the 4 waves sit on 4 different groups
     const int base = grp * 64;
-    double fx = 0.0, fy = 0.0, fz = 0.0;
+    T fx = 0, fy = 0, fz = 0;
     int rot = lane;
 #pragma unroll 2
     for (int t = 0; t < 64; t++) {
-      const D2 pxy = xy[base + rot];
-      const D2 pzm = zm[base + rot];
+      const P2<T> pxy = xy[base + rot];
+      const P2<T> pzm = zm[base + rot];
       rot = (rot + 1) & 63;
 #pragma unroll
       for (int k = 0; k < IPT; k++) {
-        const double dx = pxy.a - xi[k];
-        const double dy = pxy.b - yi[k];
-        const double dz = pzm.a - zi[k];
-        const double r2 = __builtin_fma(dz, dz, __builtin_fma(dy, dy, __builtin_fma(dx, dx, eps2)));
-        const double y0 = __builtin_amdgcn_rsq(r2);
-        const double u = y0 * y0;
-        const double e = __builtin_fma(-r2, u, 1.0);
-        const double w0 = y0 * u;
-        const double p = __builtin_fma(e, c1875, c15);
-        const double we = w0 * e;
-        const double s0 = __builtin_fma(we, p, w0);  // r^-3
-        const double si = s0 * pzm.b;
-        ax[k] = __builtin_fma(si, dx, ax[k]);
-        ay[k] = __builtin_fma(si, dy, ay[k]);
-        az[k] = __builtin_fma(si, dz, az[k]);
+        const T dx = pxy.a - xi[k];
+        const T dy = pxy.b - yi[k];
+        const T dz = pzm.a - zi[k];
+        T si, sj = 0;
+        pair_weights<SYM>(dx, dy, dz, pzm.b, mi[k], eps2, c15, c1875, &si, &sj);
+        ax[k] = fma_t(si, dx, ax[k]);
+        ay[k] = fma_t(si, dy, ay[k]);
+        az[k] = fma_t(si, dz, az[k]);
         if (SYM) {
-          const double sj = s0 * mi[k];
-          fx = __builtin_fma(-sj, dx, fx);
-          fy = __builtin_fma(-sj, dy, fy);
-          fz = __builtin_fma(-sj, dz, fz);
+          fx = fma_t(-sj, dx, fx);
+          fy = fma_t(-sj, dy, fy);
+          fz = fma_t(-sj, dz, fz);
         }
       }
       if (SYM) {  // the sums follow their body to the lane that meets it next
@@ -143,12 +175,12 @@ __device__ __forceinline__ void block_base(const SymArgs& a, int J, const double
   *m = a.mass + static_cast<int64_t>(slab) * a.S + off;
 }
 
-template <int IPT>
+template <int IPT, typename T>
 __global__ __launch_bounds__(256) void sym_tiles_kernel(const SymArgs a) {
   constexpr int B = 256 * IPT;
-  __shared__ D2 xy[B];
-  __shared__ D2 zm[B];
-  __shared__ double fJ[3][B];
+  __shared__ P2<T> xy[B];
+  __shared__ P2<T> zm[B];
+  __shared__ T fJ[3][B];
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int il = blockIdx.x, s = blockIdx.y;  // own row (local index), distance chunk
@@ -157,22 +189,23 @@ __global__ __launch_bounds__(256) void sym_tiles_kernel(const SymArgs a) {
   const int j_lo = g0 * 64, j_n = ng * 64;    // = bodies [j_lo, j_lo + j_n) of the J block
   const int I = a.row0 + il;
   const int64_t S = a.S;
-  const double eps2 = (a.eps2 > 0.0) ? a.eps2 : kTinyR2;
-  double c15 = 1.5, c1875 = 1.875;
+  // double: 2^-600 stands in for "no softening" (nbody_device.hpp); float: plain 0 + a select
+  const T eps2 = static_cast<T>((a.eps2 > 0.0) ? a.eps2 : (sizeof(T) == sizeof(double) ? kTinyR2 : 0.0));
+  T c15 = static_cast<T>(1.5), c1875 = static_cast<T>(1.875);
   asm volatile("" : "+v"(c15), "+v"(c1875));
 
-  double xi[IPT], yi[IPT], zi[IPT], mi[IPT], ax[IPT], ay[IPT], az[IPT];
+  T xi[IPT], yi[IPT], zi[IPT], mi[IPT], ax[IPT], ay[IPT], az[IPT];
   {
     const double *px, *pm;
     block_base<B>(a, I, &px, &pm);
 #pragma unroll
     for (int k = 0; k < IPT; k++) {
       const int idx = k * 256 + tid;
-      xi[k] = px[idx];
-      yi[k] = px[S + idx];
-      zi[k] = px[2 * S + idx];
-      mi[k] = pm[idx];
-      ax[k] = ay[k] = az[k] = 0.0;
+      xi[k] = static_cast<T>(px[idx]);
+      yi[k] = static_cast<T>(px[S + idx]);
+      zi[k] = static_cast<T>(px[2 * S + idx]);
+      mi[k] = static_cast<T>(pm[idx]);
+      ax[k] = ay[k] = az[k] = 0;
     }
   }
 
@@ -193,17 +226,17 @@ __global__ __launch_bounds__(256) void sym_tiles_kernel(const SymArgs a) {
       block_base<B>(a, J, &px, &pm);
       for (int o = tid; o < j_n; o += 256) {  // j_n is a multiple of 256 (jsplit <= IPT)
         const int idx = j_lo + o;
-        xy[idx] = D2{px[idx], px[S + idx]};
-        zm[idx] = D2{px[2 * S + idx], pm[idx]};
-        fJ[0][idx] = 0.0;
-        fJ[1][idx] = 0.0;
-        fJ[2][idx] = 0.0;
+        xy[idx] = P2<T>{static_cast<T>(px[idx]), static_cast<T>(px[S + idx])};
+        zm[idx] = P2<T>{static_cast<T>(px[2 * S + idx]), static_cast<T>(pm[idx])};
+        fJ[0][idx] = 0;
+        fJ[1][idx] = 0;
+        fJ[2][idx] = 0;
       }
     }
     __syncthreads();
 
-    if (sym) tile_phases<IPT, true>(xy, zm, fJ, lane, w, g0, ng, xi, yi, zi, mi, ax, ay, az, eps2, c15, c1875);
-    else tile_phases<IPT, false>(xy, zm, fJ, lane, w, g0, ng, xi, yi, zi, mi, ax, ay, az, eps2, c15, c1875);
+    if (sym) tile_phases<IPT, true, T>(xy, zm, fJ, lane, w, g0, ng, xi, yi, zi, mi, ax, ay, az, eps2, c15, c1875);
+    else tile_phases<IPT, false, T>(xy, zm, fJ, lane, w, g0, ng, xi, yi, zi, mi, ax, ay, az, eps2, c15, c1875);
 
     if (sym) {
       double* Cd = a.C + static_cast<int64_t>(d - a.c_base) * 3 * S + static_cast<int64_t>(il) * B;
@@ -385,14 +418,14 @@ bool make_plan(const nbody_mi355x_step_args& a, Plan* p) {
   return found;
 }
 
-template <int IPT>
+template <int IPT, typename T>
 hipError_t launch(SymArgs sa, const nbody_mi355x_step_args& a, hipStream_t stream, int batch, double* accum) {
   hipError_t e = hipSuccess;
   // phase 1 = what needs the own slab only (the diagonal tiles), kept in R[0];
   // phase 2 = the rest, then output; phase 0 = both
   if (a.phase == 1) {
     sa.d_lo = 0; sa.d_hi = 0; sa.dsplit = 1; sa.jsplit = 1; sa.r_base = 0; sa.c_base = 1;
-    hipLaunchKernelGGL((sym_tiles_kernel<IPT>), dim3(sa.nbs, 1, 1), dim3(256), 0, stream, sa);
+    hipLaunchKernelGGL((sym_tiles_kernel<IPT, T>), dim3(sa.nbs, 1, 1), dim3(256), 0, stream, sa);
     return hipGetLastError();
   }
   const int d_first = a.phase == 2 ? 1 : 0;
@@ -407,7 +440,7 @@ hipError_t launch(SymArgs sa, const nbody_mi355x_step_args& a, hipStream_t strea
     sa.d_hi = hi;
     sa.c_base = lo > 1 ? lo : 1;
     sa.r_first = (first && a.phase == 2) ? 0 : 1;  // the local phase's chunk joins the first batch
-    hipLaunchKernelGGL((sym_tiles_kernel<IPT>), dim3(sa.nbs, sa.dsplit, sa.jsplit), dim3(256), 0, stream, sa);
+    hipLaunchKernelGGL((sym_tiles_kernel<IPT, T>), dim3(sa.nbs, sa.dsplit, sa.jsplit), dim3(256), 0, stream, sa);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (only && a.acc_out == nullptr) {
@@ -447,8 +480,8 @@ int sym_step(const nbody_mi355x_step_args& a, hipStream_t stream) {
               "and the system at least two blocks");
     return NBODY_MI355X_ERR_INVALID;
   }
-  if (a.acc_in || a.precision != NBODY_MI355X_FP64) {
-    set_error("symmetric step: acc_in and the FP32 variant are one-sided only");
+  if (a.acc_in) {
+    set_error("symmetric step: acc_in is for one-sided steps");
     return NBODY_MI355X_ERR_INVALID;
   }
   if (a.phase < 0 || a.phase > 2) {
@@ -488,8 +521,14 @@ int sym_step(const nbody_mi355x_step_args& a, hipStream_t stream) {
   sa.c_base = 1;
   sa.eps2 = a.eps2;
   const int b = static_cast<int>(batch);
-  const hipError_t e = p.ipt == 1 ? launch<1>(sa, a, stream, b, accum)
-                       : p.ipt == 2 ? launch<2>(sa, a, stream, b, accum) : launch<4>(sa, a, stream, b, accum);
+  hipError_t e;
+  if (a.precision == NBODY_MI355X_FP32) {
+    e = p.ipt == 1 ? launch<1, float>(sa, a, stream, b, accum)
+        : p.ipt == 2 ? launch<2, float>(sa, a, stream, b, accum) : launch<4, float>(sa, a, stream, b, accum);
+  } else {
+    e = p.ipt == 1 ? launch<1, double>(sa, a, stream, b, accum)
+        : p.ipt == 2 ? launch<2, double>(sa, a, stream, b, accum) : launch<4, double>(sa, a, stream, b, accum);
+  }
   if (e != hipSuccess) {
     set_error("symmetric step launch: %s", hipGetErrorString(e));
     return NBODY_MI355X_ERR_LAUNCH;

@@ -118,8 +118,7 @@ class ShardedNBody:
         self.acc_all = None
         variant = getattr(self.backend, "variant", None)
         if (use_workspace and hasattr(self.backend, "workspace_bytes") and self.device.type == "cuda"
-                and (variant in SYM_VARIANTS or (variant == 0 and self.n >= SYM_MIN_BODIES))
-                and getattr(self.backend, "precision", FP64) == FP64):
+                and (variant in SYM_VARIANTS or (variant == 0 and self.n >= SYM_MIN_BODIES))):
             need = self.backend.workspace_bytes(S, world)
             free_b, _ = torch.cuda.mem_get_info(self.device)
             if 0 < need < free_b // 2:

@@ -120,9 +120,11 @@ def test_softening_matches_direct_formula():
     assert vec_rel(out[0, :, 6:9], a) <= 1e-13
 
 
-def test_fp32_variant_within_1e_4():
+@pytest.mark.parametrize("variant", [0, 2, 11, 12, 14])
+def test_fp32_variant_within_1e_4(variant):
+    """north_star: FP32 variant within 1e-4 after 100 steps, one-sided (2) and pair-symmetric."""
     g = load_golden("g4_plummer_4096")
-    _, out = gpu_simulate(g["particles"], g["mass"], 1, 100, float(g["dt"]), precision=nb.FP32)
+    _, out = gpu_simulate(g["particles"], g["mass"], 1, 100, float(g["dt"]), precision=nb.FP32, variant=variant)
     err = rel_pos_err(out[0, :, :3], g["out_cpu"][0, :, :3])
     assert err <= FP32_TOL
     assert err > 1e-12  # it really is the reduced-precision kernel
@@ -292,3 +294,24 @@ def test_kick_drift_integrator_option():
     assert drift_kd < 1e-4 and drift_kd < drift_eu / 10
     with pytest.raises(nb.NBodyError):
         nb.Simulation(2, 0.1, integrator=7)
+
+
+def test_fp32_symmetric_edge_cases_and_si_units():
+    """FP32 pair-symmetric kernels: coincident bodies across and inside blocks give no NaN
+    and no force; the SI-unit cloud (masses 1e24..1e26 kg, 1e8 m) stays inside float range."""
+    n = 2048
+    p, m = nb.ic_plummer(n, 77)
+    p[1500, :3] = p[3, :3]
+    p[7, :3] = p[9, :3]
+    _, ref = ol.simulate(p, m, 1, 1, 1e-3, threads=8)
+    _, out = gpu_simulate(p, m, 1, 1, 1e-3, precision=nb.FP32, variant=14)
+    assert np.all(np.isfinite(out))
+    assert vec_rel(out[0, :, 6:9], ref[0, :, 6:9]) <= 2e-5
+    g = load_golden("g8_si_cloud_512")
+    reps = 4                                   # 2048 bodies: tile the cloud on a 2e8 m lattice
+    pp = np.concatenate([g["particles"] + np.array([3e8 * k, 0, 0, 0, 0, 0]) for k in range(reps)])
+    mm = np.tile(g["mass"], reps)
+    _, ref = ol.simulate(pp, mm, 1, 20, 1.0, threads=8)
+    _, out = gpu_simulate(pp, mm, 1, 20, 1.0, precision=nb.FP32, variant=14)
+    assert np.all(np.isfinite(out))
+    assert rel_pos_err(out[0, :, :3], ref[0, :, :3]) <= FP32_TOL
