@@ -159,12 +159,12 @@ def main():
                                        + (" + reduce-scatter of pair-symmetric partial sums" if sim.acc_all is not None else "")
                                        + " per step"
                                        + ("" if args.no_overlap or world == 1 else ", all-gather overlapped with the own-slab part")),
-                       "kernel": ("pair-symmetric tiles + finish" if sim.workspace is not None and args.variant in (0, 10, 11, 12, 14)
+                       "kernel": ("pair-symmetric tiles + finish" if sim.workspace is not None and args.variant in (0, 10, 11, 12, 14, 18)
                                   else "one-sided step_kernel"),
                        "kernel_variant": args.variant},
             "roofline": {"bound": "valu_fp64" if prec == nb.FP64 else "valu_fp32", "achieved": round(ach, 3),
                          "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
-                         "kernel": ("sym_tiles_kernel+sym_finish_kernel" if sim.workspace is not None and args.variant in (0, 10, 11, 12, 14)
+                         "kernel": ("sym_tiles_kernel+sym_finish_kernel" if sim.workspace is not None and args.variant in (0, 10, 11, 12, 14, 18)
                                     else "step_kernel"), "avg_launch_ms": round(dev_s / K * 1e3, 3),
                          "flop_per_interaction": FLOP_PER_INTERACTION},
             "pct_of_fp64_vector_peak": round(100 * ach / FP64_VECTOR_PEAK_TFLOPS, 2),

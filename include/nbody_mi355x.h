@@ -129,6 +129,7 @@ typedef struct {
 #define NBODY_MI355X_VARIANT_SYM1 11 /* pair-symmetric, 256-body blocks  */
 #define NBODY_MI355X_VARIANT_SYM2 12 /* pair-symmetric, 512-body blocks  */
 #define NBODY_MI355X_VARIANT_SYM4 14 /* pair-symmetric, 1024-body blocks */
+#define NBODY_MI355X_VARIANT_SYM8 18 /* pair-symmetric, 2048-body blocks (FP64 only) */
 
 /* One small step (or one half of a split one) for the own slab's bodies:
  * a_i = sum_j m_j (r_j - r_i) / |r_j - r_i|^3 over the j ranges, then

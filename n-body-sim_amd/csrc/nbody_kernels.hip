@@ -426,14 +426,17 @@ static int check_step_args(const nbody_mi355x_step_args* a) {
   return NBODY_MI355X_OK;
 }
 
+static bool is_sym_variant(int v) {
+  return v == NBODY_MI355X_VARIANT_SYM || v == NBODY_MI355X_VARIANT_SYM1 || v == NBODY_MI355X_VARIANT_SYM2 ||
+         v == NBODY_MI355X_VARIANT_SYM4 || v == NBODY_MI355X_VARIANT_SYM8;
+}
+
 extern "C" int nbody_mi355x_step_f64(const nbody_mi355x_step_args* args, void* stream) {
   int rc = check_step_args(args);
   if (rc != NBODY_MI355X_OK) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
   hipError_t e;
-  if (args->variant >= NBODY_MI355X_VARIANT_SYM && args->variant <= NBODY_MI355X_VARIANT_SYM4 &&
-      args->variant != 13)
-    return nbody_internal::sym_step(*args, s);
+  if (is_sym_variant(args->variant)) return nbody_internal::sym_step(*args, s);
   if (args->variant == 0 && args->workspace != nullptr &&
       args->acc_in == nullptr && args->acc_out == nullptr && args->own_count >= kSymMinBodies &&
       args->j0_begin == 0 && args->j1_begin == args->j1_end &&
@@ -441,8 +444,10 @@ extern "C" int nbody_mi355x_step_f64(const nbody_mi355x_step_args* args, void* s
     // default for large single-slab systems: the pair-symmetric kernels
     nbody_mi355x_step_args a = *args;
     a.variant = NBODY_MI355X_VARIANT_SYM;
-    int64_t need = 0;
-    if (nbody_internal::sym_supported(a, &need) && need <= a.workspace_bytes) return nbody_internal::sym_step(a, s);
+    // (any workspace from the plan's minimum up will do: fewer C rows mean more batches)
+    int64_t preferred = 0, least = 0;
+    if (nbody_internal::sym_supported(a, &preferred, &least) && least <= a.workspace_bytes)
+      return nbody_internal::sym_step(a, s);
   }
   if (args->precision == NBODY_MI355X_FP32) {
     switch (args->variant) {
@@ -477,10 +482,8 @@ extern "C" int nbody_mi355x_step_workspace_bytes(const nbody_mi355x_step_args* a
   if (!args || !bytes) { set_error("step_workspace_bytes: null argument"); return NBODY_MI355X_ERR_INVALID; }
   int64_t b = 0;
   nbody_mi355x_step_args a = *args;
-  if (a.variant != NBODY_MI355X_VARIANT_SYM1 && a.variant != NBODY_MI355X_VARIANT_SYM2 &&
-      a.variant != NBODY_MI355X_VARIANT_SYM4)
-    a.variant = NBODY_MI355X_VARIANT_SYM;
-  *bytes = nbody_internal::sym_supported(a, &b) ? b : 0;
+  if (!is_sym_variant(a.variant)) a.variant = NBODY_MI355X_VARIANT_SYM;
+  *bytes = nbody_internal::sym_supported(a, &b, nullptr) ? b : 0;
   return NBODY_MI355X_OK;
 }
 

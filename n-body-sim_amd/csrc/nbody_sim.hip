@@ -113,8 +113,10 @@ extern "C" int nbody_mi355x_create(const nbody_mi355x_config* cfg, nbody_mi355x_
   s->cfg = *cfg;
   if (s->cfg.G == 0.0) s->cfg.G = NBODY_MI355X_G_REFERENCE;
   s->n = cfg->num_particles;
-  // large systems: slots in whole 1024-body blocks so that the pair-symmetric kernels apply
-  s->slots = round_up(s->n, s->n >= 8192 ? 1024 : NBODY_MI355X_TILE);
+  // large systems: slots in whole 1024- or 2048-body blocks so that the pair-symmetric
+  // kernels apply with their largest block (the padding is massless bodies, <= 3 % more)
+  s->slots = round_up(s->n, (s->n >= 65536 || cfg->variant == NBODY_MI355X_VARIANT_SYM8) ? 2048
+                            : (s->n >= 8192 ? 1024 : NBODY_MI355X_TILE));
   const size_t slab = sizeof(double) * 3 * static_cast<size_t>(s->slots);
   const int64_t eblocks = s->slots / NBODY_MI355X_TILE;
   bool ok = hipMalloc(&s->pos[0], slab) == hipSuccess && hipMalloc(&s->pos[1], slab) == hipSuccess &&
@@ -139,10 +141,11 @@ extern "C" int nbody_mi355x_create(const nbody_mi355x_config* cfg, nbody_mi355x_
     probe.shard_slots = s->slots;
     probe.num_shards = 1;
     probe.variant = cfg->variant;
+    probe.precision = cfg->precision;
     int64_t need = 0;
     size_t free_b = 0, total_b = 0;
     const bool wanted = cfg->variant == 0 || (cfg->variant >= NBODY_MI355X_VARIANT_SYM &&
-                                              cfg->variant <= NBODY_MI355X_VARIANT_SYM4);
+                                              cfg->variant <= NBODY_MI355X_VARIANT_SYM8);
     if (wanted && nbody_mi355x_step_workspace_bytes(&probe, &need) == NBODY_MI355X_OK && need > 0 &&
         hipMemGetInfo(&free_b, &total_b) == hipSuccess && static_cast<size_t>(need) < free_b / 2 &&
         hipMalloc(&s->workspace, static_cast<size_t>(need)) == hipSuccess) {

@@ -26,6 +26,20 @@
 //     results are bit-reproducible run to run.
 //   * d = 0 (the diagonal tile) is evaluated one-sided.
 //
+// Launch shape (make_plan below): grid = (own rows, dsplit distance chunks, jsplit parts of
+// a tile's j groups).  dsplit and jsplit only exist to put >= 2 waves' worth of workgroups
+// on each of the 256 CUs when there are few block rows; each extra part costs one more
+// R slab to add up.  When the C slabs for all nb/2+1 distances do not fit in the caller's
+// workspace the distances are walked in batches and the finishing kernel gathers the
+// batch's C rows into the running sums between batches (sym_gather_kernel), so any N runs
+// in a bounded workspace.  args->phase splits the step for the multi-rank path: 1 = tiles
+// that need only the own slab (the diagonal), 2 = the rest + finish, 0 = both.
+//
+// The kernels are templated on the arithmetic type T: double is the product path; float is
+// NBODY_MI355X_FP32 (state, sums and integration stay FP64, only the pair arithmetic and
+// the staged tile are FP32; the reference's float instantiation keeps
+// everything in float).
+//
 // Summation order differs from the reference's j = 0..N-1; the per-pair arithmetic is
 // the same 4-ulp r^-3 as the one-sided kernel.
 #include <hip/hip_runtime.h>
@@ -117,50 +131,79 @@ __device__ __forceinline__ void pair_weights(float dx, float dy, float dz, float
   if (WANT_J) *sj = (mi * y0) * y2;
 }
 
+// LDS layout of a staged tile: each group of 64 j bodies takes kGrp = 72 entries, of which
+// entries 64..71 repeat 0..7.  A lane that walks its group from entry r (0..63) can then
+// read 8 consecutive steps at immediate offsets without wrapping, so the inner loop has no
+// address arithmetic (2 integer instructions per 8 steps instead of 7 per 2).
+constexpr int kGrp = 72;
+
+// j groups of a tile that are staged in LDS at a time: 16 groups = 1024 bodies = 63 KB in
+// double, two workgroups per CU.  Blocks of up to 1024 bodies (IPT <= 4) are staged whole;
+// a 2048-body block (IPT = 8) goes through in two halves.
+constexpr int kStageGroups = 16;
+template <int IPT>
+constexpr int staged_groups() { return 4 * IPT < kStageGroups ? 4 * IPT : kStageGroups; }
+
 // The workgroup's j groups of the staged tile against this wave's 64*IPT bodies.  SYM = false is
 // the diagonal tile (a block against itself): i side only, no barriers needed.
+// The j-side sums travel with their body through the lanes: one DPP wave rotation per step,
+// 6 v_mov_b32_dpp (3.3 cycles each) per IPT pairs.  (Sending each step's sums to the body's
+// LDS entry with a return-less ds_add_f64 instead was tried: it removes the moves, but an
+// LDS atomic with 64-bit data holds up the SIMD's VALU issue for ~12 cycles, 3 of them cost
+// more than the 6 moves -- tools/ubench_lds.hip)
 template <int IPT, bool SYM, typename T>
-__device__ __forceinline__ void tile_phases(const P2<T>* xy, const P2<T>* zm, T (*fJ)[256 * IPT], int lane,
-                                            int w, int g0, int ng, const T (&xi)[IPT], const T (&yi)[IPT],
+__device__ __forceinline__ void tile_phases(const P2<T>* xy, const P2<T>* zm, T (*fJ)[kGrp * staged_groups<IPT>()],
+                                            int lane, int w, int ng, const T (&xi)[IPT], const T (&yi)[IPT],
                                             const T (&zi)[IPT], const T (&mi)[IPT], T (&ax)[IPT],
                                             T (&ay)[IPT], T (&az)[IPT], T eps2, T c15, T c1875) {
-  // this workgroup's share of the tile: groups g0 .. g0+ng-1 (ng a multiple of 4)
+  // the staged groups 0 .. ng-1 (ng a multiple of 4)
   for (int ph = 0; ph < ng; ph++) {
-    const int grp = g0 + (ph + (ng >> 2) * w) % ng;  // the 4 waves sit on 4 different groups
-    const int base = grp * 64;
+    const int grp = (ph + (ng >> 2) * w) % ng;  // the 4 waves sit on 4 different groups
+    const int gb = grp * kGrp;
     T fx = 0, fy = 0, fz = 0;
-    int rot = lane;
-#pragma unroll 2
-    for (int t = 0; t < 64; t++) {
-      const P2<T> pxy = xy[base + rot];
-      const P2<T> pzm = zm[base + rot];
-      rot = (rot + 1) & 63;
+    int rot = lane;  // at step t the lane meets body (lane + t) mod 64 of the group
+    // the body of the NEXT step is read while this step's pairs are evaluated
+    P2<T> jxy = xy[gb + rot];
+    P2<T> jzm = zm[gb + rot];
+    for (int t8 = 0; t8 < 8; t8++) {
+      const int rot_next = (rot + 8) & 63;
+      const P2<T>* pxy = xy + gb + rot;
+      const P2<T>* pzm = zm + gb + rot;
 #pragma unroll
-      for (int k = 0; k < IPT; k++) {
-        const T dx = pxy.a - xi[k];
-        const T dy = pxy.b - yi[k];
-        const T dz = pzm.a - zi[k];
-        T si, sj = 0;
-        pair_weights<SYM>(dx, dy, dz, pzm.b, mi[k], eps2, c15, c1875, &si, &sj);
-        ax[k] = fma_t(si, dx, ax[k]);
-        ay[k] = fma_t(si, dy, ay[k]);
-        az[k] = fma_t(si, dz, az[k]);
-        if (SYM) {
-          fx = fma_t(-sj, dx, fx);
-          fy = fma_t(-sj, dy, fy);
-          fz = fma_t(-sj, dz, fz);
+      for (int u = 0; u < 8; u++) {
+        // (after the last step this reads the group's first body again: a valid address)
+        const P2<T> nxy = u < 7 ? pxy[u + 1] : xy[gb + rot_next];
+        const P2<T> nzm = u < 7 ? pzm[u + 1] : zm[gb + rot_next];
+#pragma unroll
+        for (int k = 0; k < IPT; k++) {
+          const T dx = jxy.a - xi[k];
+          const T dy = jxy.b - yi[k];
+          const T dz = jzm.a - zi[k];
+          T si, sj = 0;
+          pair_weights<SYM>(dx, dy, dz, jzm.b, mi[k], eps2, c15, c1875, &si, &sj);
+          ax[k] = fma_t(si, dx, ax[k]);
+          ay[k] = fma_t(si, dy, ay[k]);
+          az[k] = fma_t(si, dz, az[k]);
+          if (SYM) {
+            fx = fma_t(-sj, dx, fx);
+            fy = fma_t(-sj, dy, fy);
+            fz = fma_t(-sj, dz, fz);
+          }
         }
+        if (SYM) {  // the sums follow their body to the lane that meets it next
+          fx = rotate_from_next_lane(fx);
+          fy = rotate_from_next_lane(fy);
+          fz = rotate_from_next_lane(fz);
+        }
+        jxy = nxy;
+        jzm = nzm;
       }
-      if (SYM) {  // the sums follow their body to the lane that meets it next
-        fx = rotate_from_next_lane(fx);
-        fy = rotate_from_next_lane(fy);
-        fz = rotate_from_next_lane(fz);
-      }
+      rot = rot_next;
     }
-    if (SYM) {  // 64 rotations later the sums are home: lane l holds body base + l
-      fJ[0][base + lane] += fx;
-      fJ[1][base + lane] += fy;
-      fJ[2][base + lane] += fz;
+    if (SYM) {  // 64 rotations later the sums are home: lane l holds body l of the group
+      fJ[0][gb + lane] += fx;
+      fJ[1][gb + lane] += fy;
+      fJ[2][gb + lane] += fz;
       __syncthreads();  // next phase another wave adds to this group
     }
   }
@@ -178,15 +221,16 @@ __device__ __forceinline__ void block_base(const SymArgs& a, int J, const double
 template <int IPT, typename T>
 __global__ __launch_bounds__(256) void sym_tiles_kernel(const SymArgs a) {
   constexpr int B = 256 * IPT;
-  __shared__ P2<T> xy[B];
-  __shared__ P2<T> zm[B];
-  __shared__ T fJ[3][B];
+  constexpr int G = staged_groups<IPT>();  // groups per LDS fill
+  constexpr int L = G * kGrp;                                         // LDS entries
+  __shared__ P2<T> xy[L];
+  __shared__ P2<T> zm[L];
+  __shared__ T fJ[3][L];
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int il = blockIdx.x, s = blockIdx.y;  // own row (local index), distance chunk
   const int ng = (4 * IPT) / a.jsplit;        // j groups of a tile this workgroup takes ...
   const int g0 = blockIdx.z * ng;             // ... starting here (64 bodies per group)
-  const int j_lo = g0 * 64, j_n = ng * 64;    // = bodies [j_lo, j_lo + j_n) of the J block
   const int I = a.row0 + il;
   const int64_t S = a.S;
   // double: 2^-600 stands in for "no softening" (nbody_device.hpp); float: plain 0 + a select
@@ -219,32 +263,43 @@ __global__ __launch_bounds__(256) void sym_tiles_kernel(const SymArgs a) {
     int J = I + d;
     if (J >= a.nb) J -= a.nb;
     const bool sym = (d != 0);
+    const double *px, *pm;
+    block_base<B>(a, J, &px, &pm);
+    double* Cd = a.C + static_cast<int64_t>(d - a.c_base) * 3 * S + static_cast<int64_t>(il) * B;
 
-    __syncthreads();  // every wave is done with the previous tile's LDS
-    {
-      const double *px, *pm;
-      block_base<B>(a, J, &px, &pm);
-      for (int o = tid; o < j_n; o += 256) {  // j_n is a multiple of 256 (jsplit <= IPT)
-        const int idx = j_lo + o;
-        xy[idx] = P2<T>{static_cast<T>(px[idx]), static_cast<T>(px[S + idx])};
-        zm[idx] = P2<T>{static_cast<T>(px[2 * S + idx]), static_cast<T>(pm[idx])};
-        fJ[0][idx] = 0;
-        fJ[1][idx] = 0;
-        fJ[2][idx] = 0;
-      }
-    }
-    __syncthreads();
+    for (int c0 = 0; c0 < ng; c0 += G) {  // the workgroup's groups, one LDS fill at a time
+      const int cg = ng - c0 < G ? ng - c0 : G;   // a multiple of 4 (jsplit <= IPT)
+      const int j_lo = (g0 + c0) * 64, j_n = cg * 64;  // = bodies [j_lo, j_lo + j_n) of block J
 
-    if (sym) tile_phases<IPT, true, T>(xy, zm, fJ, lane, w, g0, ng, xi, yi, zi, mi, ax, ay, az, eps2, c15, c1875);
-    else tile_phases<IPT, false, T>(xy, zm, fJ, lane, w, g0, ng, xi, yi, zi, mi, ax, ay, az, eps2, c15, c1875);
-
-    if (sym) {
-      double* Cd = a.C + static_cast<int64_t>(d - a.c_base) * 3 * S + static_cast<int64_t>(il) * B;
+      __syncthreads();  // every wave is done with the previous fill
       for (int o = tid; o < j_n; o += 256) {
         const int idx = j_lo + o;
-        Cd[idx] = fJ[0][idx];
-        Cd[S + idx] = fJ[1][idx];
-        Cd[2 * S + idx] = fJ[2][idx];
+        const int e = o & 63, q = (o >> 6) * kGrp + e;
+        const P2<T> vxy{static_cast<T>(px[idx]), static_cast<T>(px[S + idx])};
+        const P2<T> vzm{static_cast<T>(px[2 * S + idx]), static_cast<T>(pm[idx])};
+        xy[q] = vxy;
+        zm[q] = vzm;
+        fJ[0][q] = 0;
+        fJ[1][q] = 0;
+        fJ[2][q] = 0;
+        if (e < kGrp - 64) {  // the group's first entries again behind its end
+          xy[q + 64] = vxy;
+          zm[q + 64] = vzm;
+        }
+      }
+      __syncthreads();
+
+      if (sym) {
+        tile_phases<IPT, true, T>(xy, zm, fJ, lane, w, cg, xi, yi, zi, mi, ax, ay, az, eps2, c15, c1875);
+        for (int o = tid; o < j_n; o += 256) {
+          const int idx = j_lo + o;
+          const int q = (o >> 6) * kGrp + (o & 63);
+          Cd[idx] = fJ[0][q];
+          Cd[S + idx] = fJ[1][q];
+          Cd[2 * S + idx] = fJ[2][q];
+        }
+      } else {
+        tile_phases<IPT, false, T>(xy, zm, fJ, lane, w, cg, xi, yi, zi, mi, ax, ay, az, eps2, c15, c1875);
       }
     }
   }
@@ -371,8 +426,10 @@ double plan_for(const nbody_mi355x_step_args& a, int ipt, Plan* p) {
   // rises with the number of chunks up to ~16-32 and is flat beyond, and what is left is
   // the tail of one work item; so: up to 32 chunks, and tiles split until there are ~32
   // items per CU.  Model time = work / 256 CUs + one item at full CU residency.
-  const int per_cu = ipt == 4 ? 2 : (ipt == 2 ? 4 : 8);
-  const double pair_cost = ipt == 4 ? 1.00 : (ipt == 2 ? 1.06 : 1.17);  // DPP + addressing per pair
+  if (ipt == 8 && a.precision == NBODY_MI355X_FP32) return -1.0;  // (not instantiated for float)
+  const int per_cu = ipt >= 4 ? 2 : (ipt == 2 ? 4 : 8);
+  // 6 DPP moves per IPT pairs on top of 96 cycles of FP64 work per pair
+  const double pair_cost = ipt == 8 ? 0.97 : (ipt == 4 ? 1.00 : (ipt == 2 ? 1.05 : 1.15));
   const int nd = p->D + 1;
   int ds = nd < 32 ? nd : 32;
   if (const char* env = getenv("NBODY_MI355X_SYM_DSPLIT")) {  // tuning experiments only
@@ -386,7 +443,7 @@ double plan_for(const nbody_mi355x_step_args& a, int ipt, Plan* p) {
   while (js < ipt && static_cast<int64_t>(p->nbs) * nd * js < 32 * 256) js *= 2;
   if (const char* env = getenv("NBODY_MI355X_SYM_JSPLIT")) {  // tuning experiments only
     const int v = atoi(env);
-    if ((v == 1 || v == 2 || v == 4) && v <= ipt) js = v;
+    if ((v == 1 || v == 2 || v == 4 || v == 8) && v <= ipt) js = v;
   }
   p->jsplit = js;
   const double tile = static_cast<double>(B) * static_cast<double>(B) * pair_cost;
@@ -404,15 +461,16 @@ bool make_plan(const nbody_mi355x_step_args& a, Plan* p) {
   if (a.variant == NBODY_MI355X_VARIANT_SYM1) return plan_for(a, 1, p) >= 0.0;
   if (a.variant == NBODY_MI355X_VARIANT_SYM2) return plan_for(a, 2, p) >= 0.0;
   if (a.variant == NBODY_MI355X_VARIANT_SYM4) return plan_for(a, 4, p) >= 0.0;
+  if (a.variant == NBODY_MI355X_VARIANT_SYM8) return plan_for(a, 8, p) >= 0.0;
   // automatic: the fastest block size by the model whose workspace stays moderate
   // (it grows as N^2 / block; the largest block is always allowed)
   const int64_t cap = int64_t{16} << 30;
   bool found = false;
   double best = 0.0;
-  for (int ipt : {4, 2, 1}) {
+  for (int ipt : {8, 4, 2, 1}) {
     Plan c;
     const double t = plan_for(a, ipt, &c);
-    if (t < 0.0 || (ipt != 4 && c.bytes > cap)) continue;
+    if (t < 0.0 || (ipt < 4 && c.bytes > cap)) continue;
     if (!found || t < best) { found = true; best = t; *p = c; }
   }
   return found;
@@ -466,17 +524,18 @@ hipError_t launch(SymArgs sa, const nbody_mi355x_step_args& a, hipStream_t strea
 
 namespace nbody_internal {
 
-bool sym_supported(const nbody_mi355x_step_args& a, int64_t* bytes) {
+bool sym_supported(const nbody_mi355x_step_args& a, int64_t* preferred_bytes, int64_t* least_bytes) {
   Plan p;
   if (!make_plan(a, &p)) return false;
-  if (bytes) *bytes = p.bytes;
+  if (preferred_bytes) *preferred_bytes = p.bytes;
+  if (least_bytes) *least_bytes = p.row_bytes * (fixed_rows(p, a.num_shards) + 1);
   return true;
 }
 
 int sym_step(const nbody_mi355x_step_args& a, hipStream_t stream) {
   Plan p;
   if (!make_plan(a, &p)) {
-    set_error("symmetric step: shard_slots must be a multiple of the block (256, 512 or 1024 by variant) "
+    set_error("symmetric step: shard_slots must be a multiple of the block (256 .. 2048 by variant) "
               "and the system at least two blocks");
     return NBODY_MI355X_ERR_INVALID;
   }
@@ -527,7 +586,8 @@ int sym_step(const nbody_mi355x_step_args& a, hipStream_t stream) {
         : p.ipt == 2 ? launch<2, float>(sa, a, stream, b, accum) : launch<4, float>(sa, a, stream, b, accum);
   } else {
     e = p.ipt == 1 ? launch<1, double>(sa, a, stream, b, accum)
-        : p.ipt == 2 ? launch<2, double>(sa, a, stream, b, accum) : launch<4, double>(sa, a, stream, b, accum);
+        : p.ipt == 2 ? launch<2, double>(sa, a, stream, b, accum)
+        : p.ipt == 4 ? launch<4, double>(sa, a, stream, b, accum) : launch<8, double>(sa, a, stream, b, accum);
   }
   if (e != hipSuccess) {
     set_error("symmetric step launch: %s", hipGetErrorString(e));

@@ -52,7 +52,7 @@ class StepArgs(C.Structure):
     ]
 
 
-VARIANT_SYM, VARIANT_SYM1, VARIANT_SYM2, VARIANT_SYM4 = 10, 11, 12, 14
+VARIANT_SYM, VARIANT_SYM1, VARIANT_SYM2, VARIANT_SYM4, VARIANT_SYM8 = 10, 11, 12, 14, 18
 
 
 class Config(C.Structure):

@@ -33,10 +33,11 @@ import ctypes as C
 import numpy as np
 import torch
 
-from . import FP64, G_REFERENCE, TILE, VARIANT_SYM, VARIANT_SYM1, VARIANT_SYM2, VARIANT_SYM4, StepArgs, check, lib, round_up
+from . import (FP64, G_REFERENCE, TILE, VARIANT_SYM, VARIANT_SYM1, VARIANT_SYM2, VARIANT_SYM4, VARIANT_SYM8, StepArgs,
+               check, lib, round_up)
 
 SYM_MIN_BODIES = 2048  # as kSymMinBodies in csrc/nbody_kernels.hip
-SYM_VARIANTS = (VARIANT_SYM, VARIANT_SYM1, VARIANT_SYM2, VARIANT_SYM4)
+SYM_VARIANTS = (VARIANT_SYM, VARIANT_SYM1, VARIANT_SYM2, VARIANT_SYM4, VARIANT_SYM8)
 
 
 def shard_counts(n: int, world: int):
@@ -57,7 +58,7 @@ class HipBackend:
     def workspace_bytes(self, S, world):
         """Scratch the pair-symmetric kernels want for this layout (0: not applicable)."""
         a = StepArgs()
-        a.shard_slots, a.num_shards, a.variant = S, world, self.variant
+        a.shard_slots, a.num_shards, a.variant, a.precision = S, world, self.variant, self.precision
         need = C.c_int64(0)
         check(self._lib.nbody_mi355x_step_workspace_bytes(C.byref(a), C.byref(need)))
         return need.value
@@ -92,8 +93,10 @@ class ShardedNBody:
         self.backend = backend if backend is not None else HipBackend()
         self.counts, self.begins = shard_counts(self.n, world)
         self.count = self.counts[rank]
-        # large systems: whole 1024-body blocks, so that the pair-symmetric kernels apply
-        self.S = S = round_up(max(self.counts), 1024 if max(self.counts) >= 8192 else TILE)
+        # large systems: whole 1024- or 2048-body blocks, so that the pair-symmetric kernels apply
+        # with their largest block
+        big = max(self.counts)
+        self.S = S = round_up(big, 2048 if big >= 65536 else (1024 if big >= 8192 else TILE))
 
         # host image of the slab layout; padding slots: mass 0 at the origin
         pos = np.zeros((world, 3, S))

@@ -219,10 +219,12 @@ def test_error_behaviour():
 # ----------------------------------------------------------------- pair-symmetric kernels
 @pytest.mark.parametrize("variant,n", [(14, 4096), (12, 4096), (12, 3000), (14, 10000), (14, 11000),
                                        (14, 2048), (12, 1024), (0, 20000), (11, 700), (11, 5000),
-                                       (10, 9000), (10, 40000)])
+                                       (10, 9000), (10, 40000), (18, 4096), (18, 6000), (18, 11000),
+                                       (18, 70000), (0, 70000)])
 def test_symmetric_kernels_against_oracle(variant, n):
     """Newton's-third-law kernels (each unordered pair once; even and odd block counts,
-    ragged last block, the smallest legal systems) against the oracle's ordered-pair sums."""
+    ragged last block, the smallest legal systems; 18 = 2048-body blocks, staged in two
+    halves) against the oracle's ordered-pair sums."""
     p, m = nb.ic_plummer(n, 300 + n)
     _, ref = ol.simulate(p, m, 1, 10, 1e-3, threads=16)
     _, out = gpu_simulate(p, m, 1, 10, 1e-3, variant=variant)

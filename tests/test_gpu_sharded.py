@@ -117,14 +117,15 @@ def test_symmetric_multi_slab_equals_oracle(world, n):
     assert (num / np.linalg.norm(out[0, :, 6:9], axis=1)).max() <= 1e-12
 
 
-def test_symmetric_phases_equal_whole():
+@pytest.mark.parametrize("variant", [nb.VARIANT_SYM4, nb.VARIANT_SYM8])
+def test_symmetric_phases_equal_whole(variant):
     """phase 1 (diagonal tiles, own slab only) + phase 2 (the rest) == phase 0."""
     n, world, rank = 40000, 4, 2
     p, m = nb.ic_plummer(n, 21)
     s = ShardedNBody(p, m, 1e-3, rank=rank, world=world, device="cuda")
     common = dict(pos_cur=s.pos[0], pos_next=s.pos[1], mass=s.mass, vel=s.vel, S=s.S, world=world, rank=rank,
                   count=s.count, dt=s.dt, G=s.G, eps2=0.0)
-    kw = dict(acc_in=None, snapshot=None, ranges=((0, 0), (0, 0)), workspace=s.workspace, variant=nb.VARIANT_SYM4, **common)
+    kw = dict(acc_in=None, snapshot=None, ranges=((0, 0), (0, 0)), workspace=s.workspace, variant=variant, **common)
     s.backend.step(acc_out=s.acc_all, phase=0, **kw)
     whole = s.acc_all.clone()
     s.acc_all.zero_()
