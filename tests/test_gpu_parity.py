@@ -205,6 +205,30 @@ def test_full_size_sampled_rows_and_momentum(n):
     assert np.linalg.norm(f) <= 1e-12 * scale
 
 
+@pytest.mark.parametrize("n,precision", [(262144, "fp64"), (4194304, "fp64"), (4194304, "fp32")])
+def test_config5_uniform_cube_sampled_rows(n, precision):
+    """BASELINE config 5's shape (uniform cube, v = 0, equal masses, seed 7, dt = 1e-4) up to
+    its full size N = 4 194 304 on ONE GPU (the distances are walked in batches there: the
+    unbatched workspace would be 206 GB): exact accelerations of 1024 sampled rows, momentum
+    balance, and the trivially known positions (v = 0).  The net acceleration of a body deep
+    inside the cube nearly cancels, so errors are measured against the median |a|."""
+    p, m = nb.ic_uniform_cube(n, 7)
+    fp32 = precision == "fp32"
+    with nb.Simulation(n, 1e-4, precision=nb.FP32 if fp32 else nb.FP64) as sim:
+        sim.upload(p, m)
+        out = sim.run(1, snapshot=True)
+    rows = np.random.default_rng(1).choice(n, 1024, replace=False)
+    acc = ol.accel_rows(p, m, rows, threads=16)
+    scale = np.median(np.linalg.norm(acc, axis=1))
+    err = np.linalg.norm(out[rows, 6:9] - acc, axis=1).max() / scale
+    assert err <= (FP32_TOL if fp32 else 1e-12)
+    if fp32:
+        assert err > 1e-12
+    assert np.array_equal(out[:, 0:3], p[:, :3])  # v = 0: r' = r + dt * 0
+    f = (m[:, None] * out[:, 6:9]).sum(0)
+    assert np.linalg.norm(f) <= (1e-5 if fp32 else 1e-12) * (m * np.linalg.norm(out[:, 6:9], axis=1)).sum()
+
+
 def test_error_behaviour():
     with pytest.raises(nb.NBodyError) as e:
         nb.Simulation(100, 0.1, device=99)
