@@ -183,6 +183,17 @@ typedef struct {
 
 /* ref: AllocateDeviceMemory, particle_simulation_GPU.cu:13-35 (4 cudaMalloc). */
 int nbody_mi355x_create(const nbody_mi355x_config* cfg, nbody_mi355x_sim** sim);
+/* The same handle spread over several GPUs driven by one host thread (SURVEY 8b
+ * "device list", 8e; the reference has one GPU, particle_simulation_GPU.cu:13-35).
+ * devices[k] owns the k-th contiguous i-range of bodies -- the partition of the
+ * reference's CPU threads, particle_simulation.h:98-110.  Per small step the
+ * shards exchange new positions (and, on the pair-symmetric path, partial sums)
+ * by peer copies ordered with events; the host does not block inside a big
+ * step.  A device ordinal may appear more than once (several shards on one GPU:
+ * how the path is rehearsed on a one-GPU machine).  cfg->device is ignored.
+ * Every other handle function works on the result unchanged. */
+int nbody_mi355x_create_multi(const nbody_mi355x_config* cfg, const int32_t* devices,
+                              int32_t num_devices, nbody_mi355x_sim** sim);
 /* ref: FreeDeviceMemory, particle_simulation_GPU.cu:216-231. */
 int nbody_mi355x_destroy(nbody_mi355x_sim* sim);
 /* ref: CopyDataToDevice, particle_simulation_GPU.cu:40-54.  particles =

@@ -10,4 +10,12 @@ void set_error(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
 // nbody_sym.hip: pair-symmetric step (args already validated by check_step_args)
 bool sym_supported(const nbody_mi355x_step_args& a, int64_t* preferred_bytes, int64_t* least_bytes);
 int sym_step(const nbody_mi355x_step_args& a, struct ihipStream_t* stream);
+// nbody_multi.hip: the handle over several shards / GPUs (host records already double)
+struct MultiSim;
+int multi_create(const nbody_mi355x_config& cfg, const int32_t* devices, int32_t num, MultiSim** out);
+int multi_destroy(MultiSim* m);
+int multi_upload(MultiSim* m, const double* particles, const double* mass);
+int multi_run(MultiSim* m, int64_t substeps, double* snapshot_out, double* seconds);
+int multi_download(MultiSim* m, double* particles);
+int multi_energy(MultiSim* m, double* ke, double* pe);
 }  // namespace nbody_internal

@@ -1,0 +1,438 @@
+// nbody_multi.hip -- the handle API over several GPUs driven by ONE host thread
+// (nbody_mi355x_create_multi; SURVEY 8b "device list", 8e).  The reference has one GPU
+// (particle_simulation_GPU.cu:13-35); the partition is the one of its CPU threads
+// (particle_simulation.h:98-110): shard k owns the k-th contiguous i-range, remainder to the
+// low shards.  The Python driver (nbody_mi355x/sharded.py) is the same scheme with one
+// process per GPU and RCCL; here the two exchanges of a small step are peer copies between
+// the shards' streams, ordered by events, and nothing blocks the host inside a big step:
+//
+//   pair-symmetric path (large systems):
+//     A  every shard: tiles of its block rows -> partial sums for EVERY slot (acc_all)
+//     B  every shard: pulls the other shards' partial sums for ITS slab, adds them in shard
+//        order (deterministic), integrates its bodies into its slab of pos[next]
+//     C  every shard: pulls the other shards' new slabs into its pos[next]
+//   one-sided path (small systems, or no room for the workspace): A+B are one step call.
+//
+// Ordering argument (why no extra events are needed): a buffer that a peer reads in step k
+// is next written by its owner only after the owner has waited, in step k+1, on an event
+// that every peer records AFTER its step-k reads, in stream order (see multi_step).
+// A device ordinal may appear more than once: several shards on one GPU, which is how this
+// path is tested on a one-GPU machine (tests/test_gpu_multi.py).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "nbody_internal.h"
+
+using nbody_internal::set_error;
+
+namespace nbody_internal {
+
+struct Shard {
+  int device = 0;
+  int64_t count = 0, begin = 0;
+  double* pos[2] = {nullptr, nullptr};  // [P][3][S] each: every shard's slab
+  double* mass = nullptr;               // [P][S]
+  double* vel = nullptr;                // [3][S]   own bodies
+  double* acc = nullptr;                // [3][S]   own bodies' complete sums
+  double* acc_all = nullptr;            // [P][3][S] this shard's partial sums for every slot
+  double* stage = nullptr;              // [P][3][S] the other shards' partial sums for the own slab
+  double* snap = nullptr;               // [count][9] DeviceOutputParticle rows / [count][6] state rows
+  double* scratch = nullptr;            // energy partials + result
+  void* workspace = nullptr;
+  int64_t workspace_bytes = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev_partials = nullptr, ev_pos = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
+};
+
+struct MultiSim {
+  nbody_mi355x_config cfg{};
+  int64_t n = 0, S = 0;
+  int P = 0;
+  int cur = 0;
+  bool sym = false;
+  int sym_variant = NBODY_MI355X_VARIANT_SYM;
+  std::vector<Shard> sh;
+  std::vector<double> host;  // slab-layout image for uploads
+};
+
+namespace {
+
+#define M_TRY(expr, code, what)                                              \
+  do {                                                                       \
+    hipError_t e_ = (expr);                                                  \
+    if (e_ != hipSuccess) {                                                  \
+      (void)hipGetLastError();                                               \
+      set_error("multi: %s: %s", what, hipGetErrorString(e_));               \
+      return code;                                                           \
+    }                                                                        \
+  } while (0)
+
+int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
+
+bool is_sym_variant(int v) {
+  return v == NBODY_MI355X_VARIANT_SYM || v == NBODY_MI355X_VARIANT_SYM1 || v == NBODY_MI355X_VARIANT_SYM2 ||
+         v == NBODY_MI355X_VARIANT_SYM4 || v == NBODY_MI355X_VARIANT_SYM8;
+}
+
+// out[i] = sum over shards q = 0..P-1, in that order, of q's partial sums for this slab
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const double* __restrict__ own,
+                                                              const double* __restrict__ stage, int P, int r,
+                                                              int64_t len, double* __restrict__ out) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (i >= len) return;
+  double s = 0.0;
+  for (int q = 0; q < P; q++) s += (q == r) ? own[i] : stage[static_cast<int64_t>(q) * len + i];
+  out[i] = s;
+}
+
+// dst (on shard `to`) <- src (on shard `from`), on `to`'s stream
+hipError_t pull(const Shard& to, void* dst, const Shard& from, const void* src, size_t bytes) {
+  if (to.device == from.device) return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, to.stream);
+  return hipMemcpyPeerAsync(dst, to.device, src, from.device, bytes, to.stream);
+}
+
+void free_shard(Shard& s) {
+  (void)hipSetDevice(s.device);
+  if (s.stream) (void)hipStreamSynchronize(s.stream);
+  for (double** p : {&s.pos[0], &s.pos[1], &s.mass, &s.vel, &s.acc, &s.acc_all, &s.stage, &s.snap, &s.scratch}) {
+    if (*p) (void)hipFree(*p);
+    *p = nullptr;
+  }
+  if (s.workspace) (void)hipFree(s.workspace);
+  s.workspace = nullptr;
+  for (hipEvent_t* e : {&s.ev_partials, &s.ev_pos, &s.ev_t0, &s.ev_t1}) {
+    if (*e) (void)hipEventDestroy(*e);
+    *e = nullptr;
+  }
+  if (s.stream) (void)hipStreamDestroy(s.stream);
+  s.stream = nullptr;
+}
+
+nbody_mi355x_step_args base_args(const MultiSim& m, const Shard& s, int r) {
+  nbody_mi355x_step_args a;
+  memset(&a, 0, sizeof a);
+  a.pos_cur = s.pos[m.cur];
+  a.pos_next = s.pos[m.cur ^ 1];
+  a.mass = s.mass;
+  a.vel = s.vel;
+  a.shard_slots = m.S;
+  a.num_shards = m.P;
+  a.own_shard = r;
+  a.own_count = s.count;
+  a.dt = m.cfg.stepsize;
+  a.G = m.cfg.G;
+  a.eps2 = m.cfg.eps2;
+  a.precision = m.cfg.precision;
+  a.integrator = m.cfg.integrator;
+  return a;
+}
+
+// One small step of every shard, enqueued on the shards' streams.
+int multi_step(MultiSim& m, bool snapshot) {
+  const int P = m.P;
+  const int64_t S = m.S, slab = 3 * S;
+  const size_t slab_bytes = sizeof(double) * static_cast<size_t>(slab);
+  const int nxt = m.cur ^ 1;
+  if (m.sym) {
+    // A: partial sums.  acc_all of shard r was last read by its peers in step k-1 (B); r got
+    //    past C of step k-1 only after every peer's ev_pos of step k-1, recorded after those reads.
+    for (int r = 0; r < P; r++) {
+      Shard& s = m.sh[r];
+      M_TRY(hipSetDevice(s.device), NBODY_MI355X_ERR_NO_DEVICE, "hipSetDevice");
+      nbody_mi355x_step_args a = base_args(m, s, r);
+      a.acc_out = s.acc_all;
+      a.variant = m.sym_variant;
+      a.workspace = s.workspace;
+      a.workspace_bytes = s.workspace_bytes;
+      const int rc = nbody_mi355x_step_f64(&a, s.stream);
+      if (rc != NBODY_MI355X_OK) return rc;
+      M_TRY(hipEventRecord(s.ev_partials, s.stream), NBODY_MI355X_ERR_LAUNCH, "event record");
+    }
+    // B: "reduce-scatter" by pulling, then integrate.  r's slab of pos[next] was last read by
+    //    its peers in C of step k-2; each peer recorded ev_partials (waited on here) after that.
+    for (int r = 0; r < P; r++) {
+      Shard& s = m.sh[r];
+      M_TRY(hipSetDevice(s.device), NBODY_MI355X_ERR_NO_DEVICE, "hipSetDevice");
+      for (int q = 0; q < P; q++) {
+        if (q == r) continue;
+        M_TRY(hipStreamWaitEvent(s.stream, m.sh[q].ev_partials, 0), NBODY_MI355X_ERR_LAUNCH, "wait partials");
+        M_TRY(pull(s, s.stage + q * slab, m.sh[q], m.sh[q].acc_all + r * slab, slab_bytes), NBODY_MI355X_ERR_LAUNCH,
+              "pull partial sums");
+      }
+      hipLaunchKernelGGL(reduce_partials_kernel, dim3(static_cast<unsigned>((slab + 255) / 256)), dim3(256), 0,
+                         s.stream, s.acc_all + r * slab, s.stage, P, r, slab, s.acc);
+      M_TRY(hipGetLastError(), NBODY_MI355X_ERR_LAUNCH, "reduce launch");
+      nbody_mi355x_step_args a = base_args(m, s, r);
+      a.acc_in = s.acc;  // no j range: acc_in -> Euler update (+ snapshot)
+      a.variant = 1;
+      a.snapshot = snapshot ? s.snap : nullptr;
+      const int rc = nbody_mi355x_step_f64(&a, s.stream);
+      if (rc != NBODY_MI355X_OK) return rc;
+      M_TRY(hipEventRecord(s.ev_pos, s.stream), NBODY_MI355X_ERR_LAUNCH, "event record");
+    }
+  } else {
+    // one-sided: every shard sums over all slabs and integrates in one call.  r's slab of
+    // pos[next] was last read by its peers in C of step k-2; r's C of step k-1 waited on their
+    // ev_pos of step k-1, recorded after those reads.
+    for (int r = 0; r < P; r++) {
+      Shard& s = m.sh[r];
+      M_TRY(hipSetDevice(s.device), NBODY_MI355X_ERR_NO_DEVICE, "hipSetDevice");
+      nbody_mi355x_step_args a = base_args(m, s, r);
+      a.j0_begin = 0;
+      a.j0_end = static_cast<int64_t>(P) * S;
+      a.variant = is_sym_variant(m.cfg.variant) ? 0 : m.cfg.variant;
+      a.snapshot = snapshot ? s.snap : nullptr;
+      const int rc = nbody_mi355x_step_f64(&a, s.stream);
+      if (rc != NBODY_MI355X_OK) return rc;
+      M_TRY(hipEventRecord(s.ev_pos, s.stream), NBODY_MI355X_ERR_LAUNCH, "event record");
+    }
+  }
+  // C: "all-gather" by pulling the other shards' new slabs.  q's pos[next] was read by q's
+  //    own kernels of step k-1, earlier on the same stream.
+  for (int q = 0; q < P; q++) {
+    Shard& s = m.sh[q];
+    M_TRY(hipSetDevice(s.device), NBODY_MI355X_ERR_NO_DEVICE, "hipSetDevice");
+    for (int r = 0; r < P; r++) {
+      if (r == q) continue;
+      M_TRY(hipStreamWaitEvent(s.stream, m.sh[r].ev_pos, 0), NBODY_MI355X_ERR_LAUNCH, "wait positions");
+      M_TRY(pull(s, s.pos[nxt] + r * slab, m.sh[r], m.sh[r].pos[nxt] + r * slab, slab_bytes), NBODY_MI355X_ERR_LAUNCH,
+            "pull positions");
+    }
+  }
+  m.cur = nxt;
+  return NBODY_MI355X_OK;
+}
+
+int sync_all(MultiSim& m, int code, const char* what) {
+  for (Shard& s : m.sh) {
+    M_TRY(hipSetDevice(s.device), NBODY_MI355X_ERR_NO_DEVICE, "hipSetDevice");
+    M_TRY(hipStreamSynchronize(s.stream), code, what);
+  }
+  return NBODY_MI355X_OK;
+}
+
+}  // namespace
+
+int multi_destroy(MultiSim* m) {
+  if (!m) return NBODY_MI355X_OK;
+  for (Shard& s : m->sh) free_shard(s);
+  delete m;
+  return NBODY_MI355X_OK;
+}
+
+int multi_create(const nbody_mi355x_config& cfg, const int32_t* devices, int32_t num, MultiSim** out) {
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    (void)hipGetLastError();
+    set_error("create_multi: no HIP device visible");
+    return NBODY_MI355X_ERR_NO_DEVICE;
+  }
+  if (num < 1 || num > 64 || num > cfg.num_particles) {
+    set_error("create_multi: %d shards for %lld bodies", num, (long long)cfg.num_particles);
+    return NBODY_MI355X_ERR_INVALID;
+  }
+  for (int k = 0; k < num; k++)
+    if (devices[k] < 0 || devices[k] >= ndev) {
+      set_error("create_multi: device %d outside [0,%d)", devices[k], ndev);
+      return NBODY_MI355X_ERR_INVALID;
+    }
+  MultiSim* m = new (std::nothrow) MultiSim();
+  if (!m) { set_error("create_multi: out of host memory"); return NBODY_MI355X_ERR_ALLOC; }
+  m->cfg = cfg;
+  m->n = cfg.num_particles;
+  m->P = num;
+  m->sh.resize(num);
+  const int64_t base = m->n / num, rem = m->n % num;  // ref: particle_simulation.h:98-110
+  for (int r = 0; r < num; r++) {
+    m->sh[r].device = devices[r];
+    m->sh[r].count = base + (r < rem ? 1 : 0);
+    m->sh[r].begin = base * r + std::min<int64_t>(r, rem);
+  }
+  const int64_t big = m->sh[0].count;
+  m->S = round_up(big, (big >= 65536 || cfg.variant == NBODY_MI355X_VARIANT_SYM8) ? 2048
+                       : (big >= 8192 ? 1024 : NBODY_MI355X_TILE));
+  const int64_t S = m->S;
+
+  // pair-symmetric kernels: when asked for, or by default for systems they pay off on
+  nbody_mi355x_step_args probe;
+  memset(&probe, 0, sizeof probe);
+  probe.shard_slots = S;
+  probe.num_shards = num;
+  probe.precision = cfg.precision;
+  probe.variant = is_sym_variant(cfg.variant) ? cfg.variant : NBODY_MI355X_VARIANT_SYM;
+  int64_t need = 0;
+  const bool wanted = is_sym_variant(cfg.variant) || (cfg.variant == 0 && m->n >= 2048);
+  m->sym = wanted && nbody_mi355x_step_workspace_bytes(&probe, &need) == NBODY_MI355X_OK && need > 0;
+  m->sym_variant = probe.variant;
+
+  // peers that are different GPUs: direct access where the platform offers it (the pulls
+  // work without it, staged by the runtime)
+  for (int r = 0; r < num; r++)
+    for (int q = 0; q < num; q++) {
+      if (devices[r] == devices[q]) continue;
+      int can = 0;
+      if (hipSetDevice(devices[r]) == hipSuccess && hipDeviceCanAccessPeer(&can, devices[r], devices[q]) == hipSuccess &&
+          can)
+        (void)hipDeviceEnablePeerAccess(devices[q], 0);  // "already enabled" is fine
+      (void)hipGetLastError();
+    }
+
+  const size_t all = sizeof(double) * 3 * static_cast<size_t>(S) * num, one = sizeof(double) * 3 * static_cast<size_t>(S);
+  const int64_t eblocks = S / NBODY_MI355X_TILE;
+  bool ok = true;
+  for (int r = 0; r < num && ok; r++) {
+    Shard& s = m->sh[r];
+    ok = hipSetDevice(s.device) == hipSuccess && hipMalloc(&s.pos[0], all) == hipSuccess &&
+         hipMalloc(&s.pos[1], all) == hipSuccess &&
+         hipMalloc(&s.mass, sizeof(double) * static_cast<size_t>(S) * num) == hipSuccess &&
+         hipMalloc(&s.vel, one) == hipSuccess && hipMalloc(&s.acc, one) == hipSuccess &&
+         hipMalloc(&s.snap, sizeof(double) * 9 * static_cast<size_t>(s.count)) == hipSuccess &&
+         hipMalloc(&s.scratch, sizeof(double) * static_cast<size_t>(2 * eblocks + 2)) == hipSuccess &&
+         hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) == hipSuccess &&
+         hipEventCreateWithFlags(&s.ev_partials, hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags(&s.ev_pos, hipEventDisableTiming) == hipSuccess &&
+         hipEventCreate(&s.ev_t0) == hipSuccess && hipEventCreate(&s.ev_t1) == hipSuccess;
+  }
+  if (!ok) {
+    (void)hipGetLastError();
+    multi_destroy(m);
+    set_error("create_multi: device allocation failed for N=%lld over %d shards", (long long)cfg.num_particles, num);
+    return NBODY_MI355X_ERR_ALLOC;
+  }
+  // The symmetric path's buffers are taken only if they fit comfortably on EVERY shard's
+  // device; otherwise all shards run the one-sided kernel (same results to rounding).
+  for (int r = 0; r < num && m->sym; r++) {
+    Shard& s = m->sh[r];
+    size_t free_b = 0, total_b = 0;
+    const bool fits = hipSetDevice(s.device) == hipSuccess && hipMemGetInfo(&free_b, &total_b) == hipSuccess &&
+                      static_cast<size_t>(need) + 2 * all < free_b / 2;
+    if (fits && hipMalloc(&s.acc_all, all) == hipSuccess && hipMalloc(&s.stage, all) == hipSuccess &&
+        hipMalloc(&s.workspace, static_cast<size_t>(need)) == hipSuccess) {
+      s.workspace_bytes = need;
+      continue;
+    }
+    (void)hipGetLastError();
+    m->sym = false;
+    for (Shard& t : m->sh) {
+      (void)hipSetDevice(t.device);
+      if (t.acc_all) (void)hipFree(t.acc_all);
+      if (t.stage) (void)hipFree(t.stage);
+      if (t.workspace) (void)hipFree(t.workspace);
+      t.acc_all = t.stage = nullptr;
+      t.workspace = nullptr;
+      t.workspace_bytes = 0;
+    }
+  }
+  *out = m;
+  return NBODY_MI355X_OK;
+}
+
+int multi_upload(MultiSim* m, const double* particles, const double* mass) {
+  const int P = m->P;
+  const int64_t S = m->S;
+  // host image of the slab layout; padding slots: mass 0 at the origin
+  m->host.assign(static_cast<size_t>(P) * 3 * S + static_cast<size_t>(P) * S + 3 * static_cast<size_t>(S), 0.0);
+  double* hpos = m->host.data();
+  double* hmass = hpos + static_cast<size_t>(P) * 3 * S;
+  double* hvel = hmass + static_cast<size_t>(P) * S;
+  for (int r = 0; r < P; r++) {
+    const Shard& s = m->sh[r];
+    for (int64_t i = 0; i < s.count; i++) {
+      const double* p = particles + 6 * (s.begin + i);
+      for (int c = 0; c < 3; c++) hpos[(static_cast<size_t>(r) * 3 + c) * S + i] = p[c];
+      hmass[static_cast<size_t>(r) * S + i] = mass[s.begin + i];
+    }
+  }
+  for (int r = 0; r < P; r++) {
+    Shard& s = m->sh[r];
+    M_TRY(hipSetDevice(s.device), NBODY_MI355X_ERR_NO_DEVICE, "hipSetDevice");
+    for (int c = 0; c < 3; c++)
+      for (int64_t i = 0; i < S; i++) hvel[c * S + i] = i < s.count ? particles[6 * (s.begin + i) + 3 + c] : 0.0;
+    const size_t all = sizeof(double) * 3 * static_cast<size_t>(S) * P;
+    M_TRY(hipMemcpyAsync(s.pos[0], hpos, all, hipMemcpyHostToDevice, s.stream), NBODY_MI355X_ERR_H2D, "copy positions");
+    M_TRY(hipMemcpyAsync(s.pos[1], hpos, all, hipMemcpyHostToDevice, s.stream), NBODY_MI355X_ERR_H2D, "copy positions");
+    M_TRY(hipMemcpyAsync(s.mass, hmass, sizeof(double) * static_cast<size_t>(S) * P, hipMemcpyHostToDevice, s.stream),
+          NBODY_MI355X_ERR_H2D, "copy masses");
+    M_TRY(hipMemcpyAsync(s.vel, hvel, sizeof(double) * 3 * static_cast<size_t>(S), hipMemcpyHostToDevice, s.stream),
+          NBODY_MI355X_ERR_H2D, "copy velocities");
+    M_TRY(hipStreamSynchronize(s.stream), NBODY_MI355X_ERR_H2D, "upload sync");  // hvel is reused
+  }
+  m->cur = 0;
+  m->host.clear();
+  m->host.shrink_to_fit();
+  return NBODY_MI355X_OK;
+}
+
+int multi_run(MultiSim* m, int64_t substeps, double* snapshot_out, double* seconds) {
+  for (Shard& s : m->sh) {
+    M_TRY(hipSetDevice(s.device), NBODY_MI355X_ERR_NO_DEVICE, "hipSetDevice");
+    M_TRY(hipEventRecord(s.ev_t0, s.stream), NBODY_MI355X_ERR_LAUNCH, "event record");
+  }
+  for (int64_t k = 0; k < substeps; k++) {
+    const int rc = multi_step(*m, snapshot_out != nullptr && k == substeps - 1);
+    if (rc != NBODY_MI355X_OK) return rc;
+  }
+  for (Shard& s : m->sh) {
+    M_TRY(hipSetDevice(s.device), NBODY_MI355X_ERR_NO_DEVICE, "hipSetDevice");
+    M_TRY(hipEventRecord(s.ev_t1, s.stream), NBODY_MI355X_ERR_LAUNCH, "event record");
+    if (snapshot_out)
+      M_TRY(hipMemcpyAsync(snapshot_out + 9 * s.begin, s.snap, sizeof(double) * 9 * static_cast<size_t>(s.count),
+                           hipMemcpyDeviceToHost, s.stream),
+            NBODY_MI355X_ERR_D2H, "copy snapshot");
+  }
+  const int rc = sync_all(*m, NBODY_MI355X_ERR_LAUNCH, "run");
+  if (rc != NBODY_MI355X_OK) return rc;
+  double longest = 0.0;
+  for (Shard& s : m->sh) {
+    float ms = 0.f;
+    if (hipSetDevice(s.device) == hipSuccess && hipEventElapsedTime(&ms, s.ev_t0, s.ev_t1) == hipSuccess)
+      longest = std::max(longest, ms * 1e-3);
+  }
+  *seconds = longest;
+  return NBODY_MI355X_OK;
+}
+
+int multi_download(MultiSim* m, double* particles) {
+  const int64_t slab = 3 * m->S;
+  for (int r = 0; r < m->P; r++) {
+    Shard& s = m->sh[r];
+    M_TRY(hipSetDevice(s.device), NBODY_MI355X_ERR_NO_DEVICE, "hipSetDevice");
+    const int rc = nbody_mi355x_unpack_f64(s.pos[m->cur] + r * slab, s.vel, s.count, m->S, s.snap, s.stream);
+    if (rc != NBODY_MI355X_OK) return rc;
+    M_TRY(hipMemcpyAsync(particles + 6 * s.begin, s.snap, sizeof(double) * 6 * static_cast<size_t>(s.count),
+                         hipMemcpyDeviceToHost, s.stream),
+          NBODY_MI355X_ERR_D2H, "copy state");
+  }
+  return sync_all(*m, NBODY_MI355X_ERR_D2H, "download");
+}
+
+int multi_energy(MultiSim* m, double* ke, double* pe) {
+  const int64_t eblocks = m->S / NBODY_MI355X_TILE;
+  std::vector<double> h(2 * static_cast<size_t>(m->P), 0.0);
+  for (int r = 0; r < m->P; r++) {
+    Shard& s = m->sh[r];
+    M_TRY(hipSetDevice(s.device), NBODY_MI355X_ERR_NO_DEVICE, "hipSetDevice");
+    double* result = s.scratch + 2 * eblocks;
+    const int rc = nbody_mi355x_energy_f64(s.pos[m->cur], s.mass, s.vel, m->S, m->P, r, s.count, m->cfg.G, s.scratch,
+                                           result, s.stream);
+    if (rc != NBODY_MI355X_OK) return rc;
+    M_TRY(hipMemcpyAsync(&h[2 * r], result, 2 * sizeof(double), hipMemcpyDeviceToHost, s.stream), NBODY_MI355X_ERR_D2H,
+          "copy energy");
+  }
+  const int rc = sync_all(*m, NBODY_MI355X_ERR_D2H, "energy");
+  if (rc != NBODY_MI355X_OK) return rc;
+  *ke = *pe = 0.0;
+  for (int r = 0; r < m->P; r++) {  // shard order: deterministic
+    *ke += h[2 * r];
+    *pe += h[2 * r + 1];
+  }
+  return NBODY_MI355X_OK;
+}
+
+}  // namespace nbody_internal

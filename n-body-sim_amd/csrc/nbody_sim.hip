@@ -37,6 +37,7 @@ struct nbody_mi355x_sim {
   hipGraphExec_t graph[2] = {nullptr, nullptr};
   bool graph_failed = false;
   std::vector<double> host_tmp;  // float <-> double conversion of host records
+  nbody_internal::MultiSim* multi = nullptr;  // several shards / GPUs (nbody_multi.hip); the fields above are unused
 };
 
 namespace {
@@ -84,9 +85,7 @@ int free_all(nbody_mi355x_sim* s) {
 
 }  // namespace
 
-extern "C" int nbody_mi355x_create(const nbody_mi355x_config* cfg, nbody_mi355x_sim** out) {
-  if (!cfg || !out) { set_error("create: null argument"); return NBODY_MI355X_ERR_INVALID; }
-  *out = nullptr;
+static int check_config(const nbody_mi355x_config* cfg) {
   if (cfg->num_particles <= 0) { set_error("create: num_particles must be > 0"); return NBODY_MI355X_ERR_INVALID; }
   if (!(cfg->eps2 >= 0.0)) { set_error("create: eps2 must be >= 0"); return NBODY_MI355X_ERR_INVALID; }
   if (cfg->precision != NBODY_MI355X_FP64 && cfg->precision != NBODY_MI355X_FP32) {
@@ -97,6 +96,36 @@ extern "C" int nbody_mi355x_create(const nbody_mi355x_config* cfg, nbody_mi355x_
     set_error("create: unknown integrator %d", cfg->integrator);
     return NBODY_MI355X_ERR_INVALID;
   }
+  return NBODY_MI355X_OK;
+}
+
+extern "C" int nbody_mi355x_create_multi(const nbody_mi355x_config* cfg, const int32_t* devices, int32_t num_devices,
+                                         nbody_mi355x_sim** out) {
+  if (!cfg || !out || !devices) { set_error("create_multi: null argument"); return NBODY_MI355X_ERR_INVALID; }
+  *out = nullptr;
+  int rc = check_config(cfg);
+  if (rc != NBODY_MI355X_OK) return rc;
+  if (num_devices == 1) {  // one shard is the plain handle
+    nbody_mi355x_config one = *cfg;
+    one.device = devices[0];
+    return nbody_mi355x_create(&one, out);
+  }
+  nbody_mi355x_sim* s = new (std::nothrow) nbody_mi355x_sim();
+  if (!s) { set_error("create_multi: out of host memory"); return NBODY_MI355X_ERR_ALLOC; }
+  s->cfg = *cfg;
+  if (s->cfg.G == 0.0) s->cfg.G = NBODY_MI355X_G_REFERENCE;
+  s->n = cfg->num_particles;
+  rc = nbody_internal::multi_create(s->cfg, devices, num_devices, &s->multi);
+  if (rc != NBODY_MI355X_OK) { delete s; return rc; }
+  *out = s;
+  return NBODY_MI355X_OK;
+}
+
+extern "C" int nbody_mi355x_create(const nbody_mi355x_config* cfg, nbody_mi355x_sim** out) {
+  if (!cfg || !out) { set_error("create: null argument"); return NBODY_MI355X_ERR_INVALID; }
+  *out = nullptr;
+  const int vrc = check_config(cfg);
+  if (vrc != NBODY_MI355X_OK) return vrc;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
     (void)hipGetLastError();
@@ -161,6 +190,11 @@ extern "C" int nbody_mi355x_create(const nbody_mi355x_config* cfg, nbody_mi355x_
 
 extern "C" int nbody_mi355x_destroy(nbody_mi355x_sim* s) {
   if (!s) return NBODY_MI355X_OK;
+  if (s->multi) {
+    const int mrc = nbody_internal::multi_destroy(s->multi);
+    delete s;
+    return mrc;
+  }
   (void)hipSetDevice(s->cfg.device);
   if (s->stream) (void)hipStreamSynchronize(s->stream);
   int rc = free_all(s);
@@ -171,7 +205,7 @@ extern "C" int nbody_mi355x_destroy(nbody_mi355x_sim* s) {
 
 extern "C" int nbody_mi355x_upload(nbody_mi355x_sim* s, const void* particles, const void* mass) {
   if (!s || !particles || !mass) { set_error("upload: null argument"); return NBODY_MI355X_ERR_INVALID; }
-  HIP_TRY(hipSetDevice(s->cfg.device), NBODY_MI355X_ERR_NO_DEVICE, "hipSetDevice");
+  if (!s->multi) HIP_TRY(hipSetDevice(s->cfg.device), NBODY_MI355X_ERR_NO_DEVICE, "hipSetDevice");
   const size_t n = static_cast<size_t>(s->n);
   const double* hp = static_cast<const double*>(particles);
   const double* hm = static_cast<const double*>(mass);
@@ -184,6 +218,7 @@ extern "C" int nbody_mi355x_upload(nbody_mi355x_sim* s, const void* particles, c
     hp = s->host_tmp.data();
     hm = s->host_tmp.data() + 6 * n;
   }
+  if (s->multi) return nbody_internal::multi_upload(s->multi, hp, hm);
   const size_t slab = sizeof(double) * 3 * static_cast<size_t>(s->slots);
   // padding slots: mass 0 at the origin, in both position buffers, never written again
   HIP_TRY(hipMemsetAsync(s->pos[0], 0, slab, s->stream), NBODY_MI355X_ERR_H2D, "memset pos0");
@@ -204,6 +239,17 @@ extern "C" int nbody_mi355x_upload(nbody_mi355x_sim* s, const void* particles, c
 
 extern "C" int nbody_mi355x_run(nbody_mi355x_sim* s, int64_t substeps, void* snapshot_out) {
   if (!s || substeps <= 0) { set_error("run: bad arguments"); return NBODY_MI355X_ERR_INVALID; }
+  if (s->multi) {
+    const size_t n9 = 9 * static_cast<size_t>(s->n);
+    double* out = static_cast<double*>(snapshot_out);
+    if (snapshot_out && s->cfg.host_is_float) { s->host_tmp.resize(n9); out = s->host_tmp.data(); }
+    const int mrc = nbody_internal::multi_run(s->multi, substeps, out, &s->last_run_seconds);
+    if (mrc == NBODY_MI355X_OK && snapshot_out && s->cfg.host_is_float) {
+      float* o = static_cast<float*>(snapshot_out);
+      for (size_t i = 0; i < n9; i++) o[i] = static_cast<float>(s->host_tmp[i]);
+    }
+    return mrc;
+  }
   HIP_TRY(hipSetDevice(s->cfg.device), NBODY_MI355X_ERR_NO_DEVICE, "hipSetDevice");
   nbody_mi355x_step_args a;
   memset(&a, 0, sizeof a);
@@ -292,6 +338,17 @@ extern "C" int nbody_mi355x_run(nbody_mi355x_sim* s, int64_t substeps, void* sna
 
 extern "C" int nbody_mi355x_download(nbody_mi355x_sim* s, void* particles) {
   if (!s || !particles) { set_error("download: null argument"); return NBODY_MI355X_ERR_INVALID; }
+  if (s->multi) {
+    const size_t n6 = 6 * static_cast<size_t>(s->n);
+    double* out = static_cast<double*>(particles);
+    if (s->cfg.host_is_float) { s->host_tmp.resize(n6); out = s->host_tmp.data(); }
+    const int mrc = nbody_internal::multi_download(s->multi, out);
+    if (mrc == NBODY_MI355X_OK && s->cfg.host_is_float) {
+      float* o = static_cast<float*>(particles);
+      for (size_t i = 0; i < n6; i++) o[i] = static_cast<float>(s->host_tmp[i]);
+    }
+    return mrc;
+  }
   HIP_TRY(hipSetDevice(s->cfg.device), NBODY_MI355X_ERR_NO_DEVICE, "hipSetDevice");
   int rc = nbody_mi355x_unpack_f64(s->pos[s->cur], s->vel, s->n, s->slots, s->aos, s->stream);
   if (rc != NBODY_MI355X_OK) return rc;
@@ -310,6 +367,7 @@ extern "C" int nbody_mi355x_download(nbody_mi355x_sim* s, void* particles) {
 
 extern "C" int nbody_mi355x_energy(nbody_mi355x_sim* s, double* ke, double* pe) {
   if (!s || !ke || !pe) { set_error("energy: null argument"); return NBODY_MI355X_ERR_INVALID; }
+  if (s->multi) return nbody_internal::multi_energy(s->multi, ke, pe);
   HIP_TRY(hipSetDevice(s->cfg.device), NBODY_MI355X_ERR_NO_DEVICE, "hipSetDevice");
   const int64_t eblocks = s->slots / NBODY_MI355X_TILE;
   double* result = s->scratch + 2 * eblocks;

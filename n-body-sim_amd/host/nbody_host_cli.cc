@@ -119,6 +119,14 @@ std::string Simulate(ParticleSimulation<T, W>& sim, const std::string& path) {
   }
   if (path == "mi355x" || path == "mi355x-f32host") return sim.SimulateMI355X();
   if (path == "mi355x-fp32") return sim.SimulateMI355X(0, true);
+  if (path.rfind("mi355x-shards", 0) == 0) {  // mi355x-shardsK: K shards, round-robin over the visible GPUs
+    const int k = std::atoi(path.c_str() + 13);
+    int ndev = 0;
+    if (k < 1 || nbody_mi355x_device_count(&ndev) != NBODY_MI355X_OK || ndev < 1) return "bad shard count or no device";
+    std::vector<int> devs;
+    for (int i = 0; i < k; i++) devs.push_back(i % ndev);
+    return sim.SimulateMI355X(devs);
+  }
   return "unknown path " + path;
 }
 

@@ -8,6 +8,7 @@
 //
 //     std::string SimulateMI355X(int device = 0, bool fp32_forces = false,
 //                                float_t softening_squared = 0, bool kick_drift = false);
+//     std::string SimulateMI355X(const std::vector<int>& devices, ...same options...);
 //
 // the sibling of the reference's SimulateGPU(int blocksize) (ref: particle_simulation.h:559,
 // particle_simulation_GPU.cu:277-303).  It hands the particle records to
@@ -237,6 +238,14 @@ class ParticleSimulation {
   // step (same cost); the default reproduces the reference.
   std::string SimulateMI355X(int device = 0, bool fp32_forces = false, float_t softening_squared = 0,
                              bool kick_drift = false) {
+    return SimulateMI355X(std::vector<int>{device}, fp32_forces, softening_squared, kick_drift);
+  }
+
+  // The same over several GPUs driven by this one host thread: devices[k] owns the k-th
+  // contiguous i-range of bodies, the partition of the CPU paths' threads (ref:
+  // particle_simulation.h:98-110).  An ordinal may repeat (several shards on one GPU).
+  std::string SimulateMI355X(const std::vector<int>& devices, bool fp32_forces = false,
+                             float_t softening_squared = 0, bool kick_drift = false) {
     IntervallTimer device_execution_timer;
     nbody_mi355x_config cfg{};
     cfg.num_particles = num_particles_;
@@ -244,11 +253,13 @@ class ParticleSimulation {
     cfg.G = static_cast<double>(G_);
     cfg.eps2 = static_cast<double>(softening_squared);
     cfg.precision = fp32_forces ? NBODY_MI355X_FP32 : NBODY_MI355X_FP64;
-    cfg.device = device;
+    cfg.device = devices.empty() ? 0 : devices[0];
     cfg.host_is_float = std::is_same<float_t, float>::value ? 1 : 0;
     cfg.integrator = kick_drift ? NBODY_MI355X_KICK_DRIFT : NBODY_MI355X_EULER;
     nbody_mi355x_sim* sim = nullptr;
-    int rc = nbody_mi355x_create(&cfg, &sim);
+    const std::vector<int32_t> devs(devices.begin(), devices.end());
+    int rc = devs.size() > 1 ? nbody_mi355x_create_multi(&cfg, devs.data(), static_cast<int32_t>(devs.size()), &sim)
+                             : nbody_mi355x_create(&cfg, &sim);
     if (rc != NBODY_MI355X_OK) return Failure(rc, nullptr);
     rc = nbody_mi355x_upload(sim, state_[cur_].data(), mass_.data());
     if (rc != NBODY_MI355X_OK) return Failure(rc, sim);

@@ -77,6 +77,7 @@ SYMBOLS = {
     "nbody_mi355x_energy_f64": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int64,
                                           C.c_double, _P, _P, _P]),
     "nbody_mi355x_create": (C.c_int, [C.POINTER(Config), C.POINTER(_P)]),
+    "nbody_mi355x_create_multi": (C.c_int, [C.POINTER(Config), C.POINTER(C.c_int32), C.c_int32, C.POINTER(_P)]),
     "nbody_mi355x_destroy": (C.c_int, [_P]),
     "nbody_mi355x_upload": (C.c_int, [_P, _P, _P]),
     "nbody_mi355x_run": (C.c_int, [_P, C.c_int64, _P]),
@@ -156,16 +157,22 @@ def ic_uniform_cube(n: int, seed: int = 7, G: float = G_REFERENCE):
 # ---------------------------------------------------------------- handle API
 class Simulation:
     """The handle API, as ParticleSimulation::SimulateMI355X() uses it:
-    create -> upload -> run (one call per big step) -> destroy."""
+    create -> upload -> run (one call per big step) -> destroy.
+    devices = [d0, d1, ...]: one shard of bodies per entry, driven by this one host thread
+    (nbody_mi355x_create_multi; an ordinal may repeat: several shards on one GPU)."""
 
     def __init__(self, num_particles: int, stepsize: float, *, G: float = G_REFERENCE,
                  eps2: float = 0.0, precision: int = FP64, device: int = 0,
-                 host_is_float: bool = False, variant: int = 0, integrator: int = EULER):
+                 host_is_float: bool = False, variant: int = 0, integrator: int = EULER, devices=None):
         self.n = int(num_particles)
         self.host_dtype = np.float32 if host_is_float else np.float64
         cfg = Config(self.n, stepsize, G, eps2, precision, device, int(host_is_float), variant, integrator, 0)
         h = C.c_void_p()
-        check(lib().nbody_mi355x_create(C.byref(cfg), C.byref(h)))
+        if devices is None:
+            check(lib().nbody_mi355x_create(C.byref(cfg), C.byref(h)))
+        else:
+            devs = (C.c_int32 * len(devices))(*devices)
+            check(lib().nbody_mi355x_create_multi(C.byref(cfg), devs, len(devices), C.byref(h)))
         self._h = h
 
     def upload(self, particles, mass) -> None:

@@ -148,3 +148,20 @@ def test_simulate_mi355x_float_host_and_fp32_forces(tmp_path):
     assert rel_pos_err(out[1:, :, :3], cpu[1:, :, :3]) <= 1e-4
     out, _ = run_cli(tmp_path, "mi355x-f32host", g)   # ParticleSimulation<float,8>::SimulateMI355X
     assert rel_pos_err(out[1:, :, :3], cpu[1:, :, :3]) <= 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,shards", [("g4_plummer_1024", 2), ("g3_saturn_ring_500", 3), ("g4_plummer_4096", 4)])
+def test_simulate_mi355x_over_several_shards(tmp_path, name, shards):
+    """SimulateMI355X(std::vector<int> devices): the same observable effects over several
+    shards driven by one host thread (round-robin over the visible GPUs: on a one-GPU box
+    all shards share device 0)."""
+    g = load_golden(name)
+    out, status = run_cli(tmp_path, f"mi355x-shards{shards}", g)
+    assert "Simulation on MI355X succesfull." in status
+    cpu, _ = run_cli(tmp_path, "cpu", g)
+    assert rel_pos_err(out[1:, :, :3], cpu[1:, :, :3]) <= 1e-10
+    assert np.array_equal(out[0], cpu[0])
+    assert np.array_equal(out[:, :, 9], cpu[:, :, 9])
+    scale = np.linalg.norm(cpu[1:, :, 6:9], axis=-1).max()
+    assert np.abs(out[1:, :, 6:9] - cpu[1:, :, 6:9]).max() <= 1e-10 * scale
