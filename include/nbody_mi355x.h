@@ -206,6 +206,20 @@ int nbody_mi355x_upload(nbody_mi355x_sim* sim, const void* particles, const void
  * DeviceOutputParticle<T>[N] = {r, v, a*G} there (host memory).  Blocks until
  * the big step is complete (the reference's per-big-step timing needs that). */
 int nbody_mi355x_run(nbody_mi355x_sim* sim, int64_t substeps, void* snapshot_out);
+/* The same in two halves, so that the host can unpack / write big step k's
+ * snapshot while big step k+1 runs (the reference copies every
+ * snapshot at the very end, .cu:198-211): run_async enqueues the big step and the
+ * copy into snapshot_out and returns; wait blocks until both are complete.
+ * snapshot_out must stay valid and untouched until wait returns; for the copy to
+ * overlap with the host it should be page-locked (nbody_mi355x_host_alloc).
+ * One big step may be pending per handle; upload / download / energy / destroy
+ * wait for it first.  nbody_mi355x_run == run_async + wait. */
+int nbody_mi355x_run_async(nbody_mi355x_sim* sim, int64_t substeps, void* snapshot_out);
+int nbody_mi355x_wait(nbody_mi355x_sim* sim);
+/* Page-locked host memory for such buffers (hipHostMalloc / hipHostFree): no
+ * counterpart in the reference, which uses pageable new[] memory (.cu:200). */
+int nbody_mi355x_host_alloc(int64_t bytes, void** buffer);
+int nbody_mi355x_host_free(void* buffer);
 /* Current state back as Particle<T>[N]. */
 int nbody_mi355x_download(nbody_mi355x_sim* sim, void* particles);
 /* Total kinetic and potential energy of the current state. */

@@ -369,7 +369,8 @@ int multi_upload(MultiSim* m, const double* particles, const double* mass) {
   return NBODY_MI355X_OK;
 }
 
-int multi_run(MultiSim* m, int64_t substeps, double* snapshot_out, double* seconds) {
+// Enqueues a big step on every shard's stream and returns; multi_wait completes it.
+int multi_enqueue(MultiSim* m, int64_t substeps, double* snapshot_out) {
   for (Shard& s : m->sh) {
     M_TRY(hipSetDevice(s.device), NBODY_MI355X_ERR_NO_DEVICE, "hipSetDevice");
     M_TRY(hipEventRecord(s.ev_t0, s.stream), NBODY_MI355X_ERR_LAUNCH, "event record");
@@ -386,6 +387,10 @@ int multi_run(MultiSim* m, int64_t substeps, double* snapshot_out, double* secon
                            hipMemcpyDeviceToHost, s.stream),
             NBODY_MI355X_ERR_D2H, "copy snapshot");
   }
+  return NBODY_MI355X_OK;
+}
+
+int multi_wait(MultiSim* m, double* seconds) {
   const int rc = sync_all(*m, NBODY_MI355X_ERR_LAUNCH, "run");
   if (rc != NBODY_MI355X_OK) return rc;
   double longest = 0.0;

@@ -37,6 +37,9 @@ struct nbody_mi355x_sim {
   hipGraphExec_t graph[2] = {nullptr, nullptr};
   bool graph_failed = false;
   std::vector<double> host_tmp;  // float <-> double conversion of host records
+  // a big step enqueued by run_async and not yet completed by wait
+  bool pending = false;
+  void* pending_out = nullptr;
   nbody_internal::MultiSim* multi = nullptr;  // several shards / GPUs (nbody_multi.hip); the fields above are unused
 };
 
@@ -190,6 +193,7 @@ extern "C" int nbody_mi355x_create(const nbody_mi355x_config* cfg, nbody_mi355x_
 
 extern "C" int nbody_mi355x_destroy(nbody_mi355x_sim* s) {
   if (!s) return NBODY_MI355X_OK;
+  if (s->pending) (void)nbody_mi355x_wait(s);
   if (s->multi) {
     const int mrc = nbody_internal::multi_destroy(s->multi);
     delete s;
@@ -205,6 +209,7 @@ extern "C" int nbody_mi355x_destroy(nbody_mi355x_sim* s) {
 
 extern "C" int nbody_mi355x_upload(nbody_mi355x_sim* s, const void* particles, const void* mass) {
   if (!s || !particles || !mass) { set_error("upload: null argument"); return NBODY_MI355X_ERR_INVALID; }
+  if (s->pending) { const int wrc = nbody_mi355x_wait(s); if (wrc != NBODY_MI355X_OK) return wrc; }
   if (!s->multi) HIP_TRY(hipSetDevice(s->cfg.device), NBODY_MI355X_ERR_NO_DEVICE, "hipSetDevice");
   const size_t n = static_cast<size_t>(s->n);
   const double* hp = static_cast<const double*>(particles);
@@ -238,16 +243,61 @@ extern "C" int nbody_mi355x_upload(nbody_mi355x_sim* s, const void* particles, c
 }
 
 extern "C" int nbody_mi355x_run(nbody_mi355x_sim* s, int64_t substeps, void* snapshot_out) {
+  const int rc = nbody_mi355x_run_async(s, substeps, snapshot_out);
+  return rc != NBODY_MI355X_OK ? rc : nbody_mi355x_wait(s);
+}
+
+extern "C" int nbody_mi355x_wait(nbody_mi355x_sim* s) {
+  if (!s) { set_error("wait: null argument"); return NBODY_MI355X_ERR_INVALID; }
+  if (!s->pending) return NBODY_MI355X_OK;
+  s->pending = false;
+  if (s->multi) {
+    const int mrc = nbody_internal::multi_wait(s->multi, &s->last_run_seconds);
+    if (mrc != NBODY_MI355X_OK) return mrc;
+  } else {
+    HIP_TRY(hipSetDevice(s->cfg.device), NBODY_MI355X_ERR_NO_DEVICE, "hipSetDevice");
+    hipError_t e = hipStreamSynchronize(s->stream);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      set_error("run: %s", hipGetErrorString(e));
+      return NBODY_MI355X_ERR_LAUNCH;
+    }
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, s->ev0, s->ev1) == hipSuccess) s->last_run_seconds = ms * 1e-3;
+  }
+  if (s->pending_out && s->cfg.host_is_float) {
+    float* o = static_cast<float*>(s->pending_out);
+    for (size_t i = 0; i < 9 * static_cast<size_t>(s->n); i++) o[i] = static_cast<float>(s->host_tmp[i]);
+  }
+  s->pending_out = nullptr;
+  return NBODY_MI355X_OK;
+}
+
+extern "C" int nbody_mi355x_host_alloc(int64_t bytes, void** out) {
+  if (!out || bytes <= 0) { set_error("host_alloc: bad arguments"); return NBODY_MI355X_ERR_INVALID; }
+  *out = nullptr;
+  HIP_TRY(hipHostMalloc(out, static_cast<size_t>(bytes), hipHostMallocDefault), NBODY_MI355X_ERR_ALLOC, "hipHostMalloc");
+  return NBODY_MI355X_OK;
+}
+
+extern "C" int nbody_mi355x_host_free(void* p) {
+  if (!p) return NBODY_MI355X_OK;
+  HIP_TRY(hipHostFree(p), NBODY_MI355X_ERR_FREE, "hipHostFree");
+  return NBODY_MI355X_OK;
+}
+
+extern "C" int nbody_mi355x_run_async(nbody_mi355x_sim* s, int64_t substeps, void* snapshot_out) {
   if (!s || substeps <= 0) { set_error("run: bad arguments"); return NBODY_MI355X_ERR_INVALID; }
+  if (s->pending) { set_error("run: the previous run_async has not been waited for"); return NBODY_MI355X_ERR_INVALID; }
   if (s->multi) {
     const size_t n9 = 9 * static_cast<size_t>(s->n);
     double* out = static_cast<double*>(snapshot_out);
     if (snapshot_out && s->cfg.host_is_float) { s->host_tmp.resize(n9); out = s->host_tmp.data(); }
-    const int mrc = nbody_internal::multi_run(s->multi, substeps, out, &s->last_run_seconds);
-    if (mrc == NBODY_MI355X_OK && snapshot_out && s->cfg.host_is_float) {
-      float* o = static_cast<float*>(snapshot_out);
-      for (size_t i = 0; i < n9; i++) o[i] = static_cast<float>(s->host_tmp[i]);
-    }
+    const int mrc = nbody_internal::multi_enqueue(s->multi, substeps, out);
+    // (on an error part of the step may be enqueued: wait() drains it)
+    s->pending = true;
+    s->pending_out = mrc == NBODY_MI355X_OK ? snapshot_out : nullptr;
+    if (mrc != NBODY_MI355X_OK) { (void)nbody_internal::multi_wait(s->multi, &s->last_run_seconds); s->pending = false; }
     return mrc;
   }
   HIP_TRY(hipSetDevice(s->cfg.device), NBODY_MI355X_ERR_NO_DEVICE, "hipSetDevice");
@@ -321,23 +371,14 @@ extern "C" int nbody_mi355x_run(nbody_mi355x_sim* s, int64_t substeps, void* sna
               NBODY_MI355X_ERR_D2H, "copy snapshot");
     }
   }
-  hipError_t e = hipStreamSynchronize(s->stream);
-  if (e != hipSuccess) {
-    (void)hipGetLastError();
-    set_error("run: %s", hipGetErrorString(e));
-    return NBODY_MI355X_ERR_LAUNCH;
-  }
-  if (snapshot_out && s->cfg.host_is_float) {
-    float* o = static_cast<float*>(snapshot_out);
-    for (size_t i = 0; i < 9 * static_cast<size_t>(s->n); i++) o[i] = static_cast<float>(s->host_tmp[i]);
-  }
-  float ms = 0.f;
-  if (hipEventElapsedTime(&ms, s->ev0, s->ev1) == hipSuccess) s->last_run_seconds = ms * 1e-3;
+  s->pending = true;
+  s->pending_out = snapshot_out;
   return NBODY_MI355X_OK;
 }
 
 extern "C" int nbody_mi355x_download(nbody_mi355x_sim* s, void* particles) {
   if (!s || !particles) { set_error("download: null argument"); return NBODY_MI355X_ERR_INVALID; }
+  if (s->pending) { const int wrc = nbody_mi355x_wait(s); if (wrc != NBODY_MI355X_OK) return wrc; }
   if (s->multi) {
     const size_t n6 = 6 * static_cast<size_t>(s->n);
     double* out = static_cast<double*>(particles);
@@ -367,6 +408,7 @@ extern "C" int nbody_mi355x_download(nbody_mi355x_sim* s, void* particles) {
 
 extern "C" int nbody_mi355x_energy(nbody_mi355x_sim* s, double* ke, double* pe) {
   if (!s || !ke || !pe) { set_error("energy: null argument"); return NBODY_MI355X_ERR_INVALID; }
+  if (s->pending) { const int wrc = nbody_mi355x_wait(s); if (wrc != NBODY_MI355X_OK) return wrc; }
   if (s->multi) return nbody_internal::multi_energy(s->multi, ke, pe);
   HIP_TRY(hipSetDevice(s->cfg.device), NBODY_MI355X_ERR_NO_DEVICE, "hipSetDevice");
   const int64_t eblocks = s->slots / NBODY_MI355X_TILE;

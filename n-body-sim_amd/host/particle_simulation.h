@@ -266,31 +266,63 @@ class ParticleSimulation {
 
     SaveFirstStep();
     IntervallTimer sim_timer;
-    std::vector<DeviceOutputParticle<float_t>> snapshot(num_particles_);
+    // Two page-locked snapshot buffers: while big step k+1 runs on the device, big step
+    // k's records are unpacked into out_put_data_ here (the reference unpacks everything
+    // after the last step, ref: .cu:239-266, holding all snapshots on the device).
+    DeviceOutputParticle<float_t>* snapshot[2] = {nullptr, nullptr};
+    bool pinned[2] = {false, false};
+    std::vector<DeviceOutputParticle<float_t>> pageable[2];  // if page-locked memory is refused
+    const int64_t snap_bytes = static_cast<int64_t>(sizeof(DeviceOutputParticle<float_t>)) * num_particles_;
+    for (int b = 0; b < 2; b++) {
+      void* p = nullptr;
+      pinned[b] = nbody_mi355x_host_alloc(snap_bytes, &p) == NBODY_MI355X_OK;
+      if (pinned[b]) {
+        snapshot[b] = static_cast<DeviceOutputParticle<float_t>*>(p);
+      } else {
+        pageable[b].resize(num_particles_);
+        snapshot[b] = pageable[b].data();
+      }
+    }
+    auto unpin = [&]() {
+      for (int b = 0; b < 2; b++)
+        if (pinned[b]) { nbody_mi355x_host_free(snapshot[b]); pinned[b] = false; }
+    };
+    IntervallTimer big_step_timer;
+    if (num_big_steps_ > 0) {
+      rc = nbody_mi355x_run_async(sim, num_substeps_per_big_step_, snapshot[1]);
+      if (rc != NBODY_MI355X_OK) { unpin(); return Failure(rc, sim); }
+    }
     for (int64_t k = 1; k <= num_big_steps_; k++) {
-      IntervallTimer big_step_timer;
-      rc = nbody_mi355x_run(sim, num_substeps_per_big_step_, snapshot.data());
-      if (rc != NBODY_MI355X_OK) return Failure(rc, sim);
+      rc = nbody_mi355x_wait(sim);  // big step k is complete, its snapshot in snapshot[k & 1]
+      if (rc != NBODY_MI355X_OK) { unpin(); return Failure(rc, sim); }
+      execution_time_[k - 1] = static_cast<double>(big_step_timer.getTimeInMicroseconds()) * 1.0e-06;
+      big_step_timer = IntervallTimer();
+      if (k < num_big_steps_) {
+        rc = nbody_mi355x_run_async(sim, num_substeps_per_big_step_, snapshot[(k + 1) & 1]);
+        if (rc != NBODY_MI355X_OK) { unpin(); return Failure(rc, sim); }
+      }
+      const DeviceOutputParticle<float_t>* snap = snapshot[k & 1];
       for (int i = 0; i < num_particles_; i++) {
         OutPutParticle<float_t>& o = out_put_data_[k][i];
         for (int c = 0; c < 3; c++) {
-          o.r[c] = snapshot[i].r[c];
-          o.v[c] = snapshot[i].v[c];
-          o.a[c] = snapshot[i].a[c];
+          o.r[c] = snap[i].r[c];
+          o.v[c] = snap[i].v[c];
+          o.a[c] = snap[i].a[c];
         }
         o.m = mass_[i];
         o.t = stepsize_ * num_substeps_per_big_step_ * k;
       }
-      execution_time_[k - 1] = static_cast<double>(big_step_timer.getTimeInMicroseconds()) * 1.0e-06;
       PrintSimulationProgress(static_cast<int>(k));
     }
     total_execution_time_ = sim_timer.getTimeInSeconds();
     // leave the object holding the final state, as the CPU paths do
+    const DeviceOutputParticle<float_t>* last = snapshot[num_big_steps_ & 1];
     for (int i = 0; i < num_particles_ && num_big_steps_ > 0; i++)
       for (int c = 0; c < 3; c++) {
-        state_[cur_][i].r[c] = snapshot[i].r[c];
-        state_[cur_][i].v[c] = snapshot[i].v[c];
+        state_[cur_][i].r[c] = last[i].r[c];
+        state_[cur_][i].v[c] = last[i].v[c];
       }
+    unpin();
     rc = nbody_mi355x_destroy(sim);
     if (rc != NBODY_MI355X_OK) return Failure(rc, nullptr);
     std::cout << "Device execution time: " << device_execution_timer.getTimeInSeconds() << "s" << std::endl;

@@ -81,6 +81,10 @@ SYMBOLS = {
     "nbody_mi355x_destroy": (C.c_int, [_P]),
     "nbody_mi355x_upload": (C.c_int, [_P, _P, _P]),
     "nbody_mi355x_run": (C.c_int, [_P, C.c_int64, _P]),
+    "nbody_mi355x_run_async": (C.c_int, [_P, C.c_int64, _P]),
+    "nbody_mi355x_wait": (C.c_int, [_P]),
+    "nbody_mi355x_host_alloc": (C.c_int, [C.c_int64, C.POINTER(_P)]),
+    "nbody_mi355x_host_free": (C.c_int, [_P]),
     "nbody_mi355x_download": (C.c_int, [_P, _P]),
     "nbody_mi355x_energy": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "nbody_mi355x_last_run_seconds": (C.c_int, [_P, C.POINTER(C.c_double)]),
@@ -154,6 +158,30 @@ def ic_uniform_cube(n: int, seed: int = 7, G: float = G_REFERENCE):
     return p, m
 
 
+class PinnedArray:
+    """A page-locked (n, cols) host array from nbody_mi355x_host_alloc; .array is the numpy view.
+    Free it with close() (or use it as a context manager) once no copy into it is pending."""
+
+    def __init__(self, shape, dtype=np.float64):
+        self._p = C.c_void_p()
+        nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        check(lib().nbody_mi355x_host_alloc(nbytes, C.byref(self._p)))
+        raw = (C.c_char * nbytes).from_address(self._p.value)
+        self.array = np.frombuffer(raw, dtype=dtype).reshape(shape)
+
+    def close(self) -> None:
+        if self._p:
+            p, self._p = self._p, None
+            self.array = None
+            check(lib().nbody_mi355x_host_free(p))
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
 # ---------------------------------------------------------------- handle API
 class Simulation:
     """The handle API, as ParticleSimulation::SimulateMI355X() uses it:
@@ -185,6 +213,15 @@ class Simulation:
         out = np.empty((self.n, 9), dtype=self.host_dtype) if snapshot else None
         check(lib().nbody_mi355x_run(self._h, substeps, out.ctypes.data_as(_P) if snapshot else None))
         return out
+
+    def run_async(self, substeps: int, out=None):
+        """Enqueue one big step; `out` ((n,9) array of the host dtype, ideally a PinnedArray's) receives the snapshot.  wait() completes it."""
+        if out is not None:
+            assert out.shape == (self.n, 9) and out.dtype == self.host_dtype and out.flags.c_contiguous
+        check(lib().nbody_mi355x_run_async(self._h, substeps, out.ctypes.data_as(_P) if out is not None else None))
+
+    def wait(self) -> None:
+        check(lib().nbody_mi355x_wait(self._h))
 
     def download(self):
         p = np.empty((self.n, 6), dtype=self.host_dtype)

@@ -341,3 +341,38 @@ def test_fp32_symmetric_edge_cases_and_si_units():
     _, out = gpu_simulate(pp, mm, 1, 20, 1.0, precision=nb.FP32, variant=14)
     assert np.all(np.isfinite(out))
     assert rel_pos_err(out[0, :, :3], ref[0, :, :3]) <= FP32_TOL
+
+
+@pytest.mark.parametrize("devices", [None, [0, 0, 0]])
+def test_run_async_overlaps_and_matches_run(devices):
+    """run_async + wait == run, big step after big step, with page-locked snapshot buffers
+    that alternate (the host mirror's pipeline: unpack step k while step k+1 runs)."""
+    n = 5000
+    p, m = nb.ic_plummer(n, 9)
+    kw = {} if devices is None else {"devices": devices}
+    with nb.Simulation(n, 1e-3, **kw) as sim:
+        sim.upload(p, m)
+        ref = [sim.run(7, snapshot=True) for _ in range(4)]
+    pinned = [nb.PinnedArray((n, 9)), nb.PinnedArray((n, 9))]
+    bufs = [q.array for q in pinned]
+    try:
+        with nb.Simulation(n, 1e-3, **kw) as sim:
+            sim.upload(p, m)
+            got = []
+            sim.run_async(7, bufs[0])
+            with pytest.raises(nb.NBodyError):
+                sim.run_async(7, bufs[1])          # one pending big step per handle
+            for k in range(4):
+                sim.wait()
+                if k < 3:
+                    sim.run_async(7, bufs[(k + 1) & 1])
+                got.append(bufs[k & 1].copy())     # "unpack" while the next big step runs
+            sim.wait()                             # nothing pending: a no-op
+            fin = sim.download()
+    finally:
+        bufs = None
+        for q in pinned:
+            q.close()
+    for a, b in zip(ref, got):
+        assert np.array_equal(a, b)
+    assert np.array_equal(fin[:, :3], got[-1][:, :3])
