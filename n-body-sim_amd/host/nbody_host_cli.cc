@@ -8,7 +8,7 @@
 //       write the initial conditions of a reference scene (earth_moon | earth_7moons |
 //       slingshoot | saturn_ring) as  int64 n, double[n][6] {r,v}, double[n] m
 //   nbody_host_cli run    PATH IN.bin BIG SUB DT THREADS OUT.bin
-//       PATH = cpu | avx2 | mi355x | mi355x-fp32 | cpu-f32 | mi355x-f32host
+//       PATH = cpu | avx2 | avx512 | mi355x | mi355x-fp32 | mi355x-shardsK | cpu-f32 | avx512-f32 | mi355x-f32host
 //       read IN.bin (format above), simulate BIG big steps of SUB small steps, write
 //       OutPutParticle rows double[(BIG+1)][n][11] {r,v,a,m,t} (float runs are widened)
 //   nbody_host_cli demo   NAME PATH [BIG] [SUB_DIVISOR] [OUTDIR]
@@ -117,6 +117,7 @@ std::string Simulate(ParticleSimulation<T, W>& sim, const std::string& path) {
   if constexpr (std::is_same<T, double>::value && W == 4) {
     if (path == "avx2") { sim.SimulateAVX2(); return "ok"; }
   }
+  if (path == "avx512" || path == "avx512-f32") return sim.SimulateAVX512() ? "ok" : "no AVX-512F on this CPU";
   if (path == "mi355x" || path == "mi355x-f32host") return sim.SimulateMI355X();
   if (path == "mi355x-fp32") return sim.SimulateMI355X(0, true);
   if (path.rfind("mi355x-shards", 0) == 0) {  // mi355x-shardsK: K shards, round-robin over the visible GPUs
@@ -171,7 +172,7 @@ int main(int argc, char** argv) {
     const int64_t big = atoll(argv[4]), sub = atoll(argv[5]);
     const double dt = atof(argv[6]);
     const int threads = atoi(argv[7]);
-    if (path == "cpu-f32" || path == "mi355x-f32host") return RunRaw<float, 8>(path, p, m, big, sub, dt, threads, argv[8]);
+    if (path == "cpu-f32" || path == "avx512-f32" || path == "mi355x-f32host") return RunRaw<float, 8>(path, p, m, big, sub, dt, threads, argv[8]);
     return RunRaw<double, 4>(path, p, m, big, sub, dt, threads, argv[8]);
   }
   if (cmd == "demo" && argc >= 4) {

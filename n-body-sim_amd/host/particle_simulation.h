@@ -26,18 +26,22 @@
 
 #include <immintrin.h>
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cmath>
 #include <condition_variable>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
+#include <cstring>
 #include <fstream>
 #include <functional>
 #include <iomanip>
 #include <iostream>
 #include <memory>
 #include <mutex>
+#include <new>
 #include <sstream>
 #include <string>
 #include <thread>
@@ -157,6 +161,72 @@ inline void Share(int total, int parts, int id, int* first, int* count) {
   *first = id * base + (id < extra ? id : extra);
 }
 
+// ---- AVX-512 building blocks for SimulateAVX512() (the reference's own TODO, ref:
+// particle_simulation.h:430-431).  Compiled for avx512f per function, so the header still
+// builds with the reference's flags (-mavx2) and the binary still runs on AVX2-only hosts.
+#define NBODY_HOST_AVX512 __attribute__((target("avx512f")))
+#define NBODY_HOST_AVX512_INLINE __attribute__((target("avx512f"), always_inline)) static inline
+
+template <typename T>
+struct Vec512;
+template <>
+struct Vec512<double> {
+  using reg = __m512d;
+  static constexpr int kLanes = 8;
+  NBODY_HOST_AVX512_INLINE reg Set1(double v) { return _mm512_set1_pd(v); }
+  NBODY_HOST_AVX512_INLINE reg Load(const double* p) { return _mm512_load_pd(p); }
+  NBODY_HOST_AVX512_INLINE reg Sub(reg a, reg b) { return _mm512_sub_pd(a, b); }
+  NBODY_HOST_AVX512_INLINE reg Mul(reg a, reg b) { return _mm512_mul_pd(a, b); }
+  NBODY_HOST_AVX512_INLINE reg Fma(reg a, reg b, reg c) { return _mm512_fmadd_pd(a, b, c); }
+  // m / (r2 * sqrt(r2)) in the lanes with r2 > 0, exactly 0 in the others: the reference's
+  // "skip pairs with r^2 == 0" (ref: :269, :427-460) without a branch
+  NBODY_HOST_AVX512_INLINE reg Weight(reg m, reg r2) {
+    const __mmask8 k = _mm512_cmp_pd_mask(r2, _mm512_setzero_pd(), _CMP_GT_OQ);
+    return _mm512_maskz_div_pd(k, m, _mm512_mul_pd(r2, _mm512_sqrt_pd(r2)));
+  }
+  NBODY_HOST_AVX512_INLINE double Sum(reg a) { return _mm512_reduce_add_pd(a); }
+};
+template <>
+struct Vec512<float> {
+  using reg = __m512;
+  static constexpr int kLanes = 16;
+  NBODY_HOST_AVX512_INLINE reg Set1(float v) { return _mm512_set1_ps(v); }
+  NBODY_HOST_AVX512_INLINE reg Load(const float* p) { return _mm512_load_ps(p); }
+  NBODY_HOST_AVX512_INLINE reg Sub(reg a, reg b) { return _mm512_sub_ps(a, b); }
+  NBODY_HOST_AVX512_INLINE reg Mul(reg a, reg b) { return _mm512_mul_ps(a, b); }
+  NBODY_HOST_AVX512_INLINE reg Fma(reg a, reg b, reg c) { return _mm512_fmadd_ps(a, b, c); }
+  NBODY_HOST_AVX512_INLINE reg Weight(reg m, reg r2) {
+    const __mmask16 k = _mm512_cmp_ps_mask(r2, _mm512_setzero_ps(), _CMP_GT_OQ);
+    return _mm512_maskz_div_ps(k, m, _mm512_mul_ps(r2, _mm512_sqrt_ps(r2)));
+  }
+  NBODY_HOST_AVX512_INLINE float Sum(reg a) { return _mm512_reduce_add_ps(a); }
+};
+
+// 64-byte aligned array of T, zero-initialised
+template <typename T>
+struct AlignedArray {
+  explicit AlignedArray(size_t n = 0) { Reset(n); }
+  AlignedArray(const AlignedArray&) = delete;
+  AlignedArray& operator=(const AlignedArray&) = delete;
+  ~AlignedArray() { std::free(p_); }
+  void Reset(size_t n) {
+    std::free(p_);
+    p_ = nullptr;
+    if (n == 0) return;
+    const size_t bytes = (n * sizeof(T) + 63) / 64 * 64;
+    p_ = static_cast<T*>(std::aligned_alloc(64, bytes));
+    if (!p_) throw std::bad_alloc();
+    std::memset(p_, 0, bytes);
+  }
+  T* data() { return p_; }
+  const T* data() const { return p_; }
+  T& operator[](size_t i) { return p_[i]; }
+  const T& operator[](size_t i) const { return p_[i]; }
+
+ private:
+  T* p_ = nullptr;
+};
+
 }  // namespace nbody_host_detail
 
 template <typename float_t, int SIMD_float_t_width>
@@ -227,6 +297,50 @@ class ParticleSimulation {
       const int l = i % 4;
       state_[cur_][i] = Particle<float_t>{{b.r_x[l], b.r_y[l], b.r_z[l]}, {b.v_x[l], b.v_y[l], b.v_z[l]}};
     }
+  }
+
+  // No counterpart in the reference (its TODO, ref: :430-431): the same small step with
+  // 512-bit vectors -- 8 doubles or 16 floats of j bodies per instruction, for double AND
+  // float objects of any batch width (the reference's SIMD path is <double,4> only), 4 i
+  // bodies per pass over the j bodies so that each load is used four times, the
+  // r^2 == 0 rule as a lane mask instead of a scalar fallback, any N (no N % 4 caveat).
+  // Arithmetic per pair as SimulateAVX2 (r^2 by two FMAs on dx*dx, m / (r^2 sqrt(r^2)),
+  // FMA accumulation, G * sum); the partial sums are 8 / 16 instead of 4, so results agree
+  // with SimulateAVX2 / SimulateCPU to rounding (~1e-13 after 100 steps), not bit for bit.
+  // Returns false (and does nothing) if the CPU has no AVX-512F.
+  bool SimulateAVX512() {
+    if (!__builtin_cpu_supports("avx512f")) return false;
+    using V = nbody_host_detail::Vec512<float_t>;
+    const size_t padded = (static_cast<size_t>(num_particles_) + V::kLanes - 1) / V::kLanes * V::kLanes;
+    for (int b = 0; b < 2; b++)
+      for (int c = 0; c < 3; c++) soa_r_[b][c].Reset(padded);  // padding: massless bodies at the origin
+    for (int c = 0; c < 3; c++) soa_v_[c].Reset(padded);
+    soa_m_.Reset(padded);
+    scur_ = 0;
+    for (int i = 0; i < num_particles_; i++) {
+      for (int c = 0; c < 3; c++) {
+        soa_r_[0][c][i] = state_[cur_][i].r[c];
+        soa_v_[c][i] = state_[cur_][i].v[c];
+      }
+      soa_m_[i] = mass_[i];
+    }
+    RunHost([this](bool last) {
+      pool_.Run([this, last](int id) { SmallStepAVX512(id, last); });
+      scur_ ^= 1;
+    });
+    // keep the flat and the batched records in step with the vector ones
+    for (int i = 0; i < num_particles_; i++) {
+      Particle<float_t>& q = state_[cur_][i];
+      for (int c = 0; c < 3; c++) {
+        q.r[c] = soa_r_[scur_][c][i];
+        q.v[c] = soa_v_[c][i];
+      }
+      Batch& b = batches_[bcur_][i / SIMD_float_t_width];
+      const int l = i % SIMD_float_t_width;
+      b.r_x[l] = q.r[0]; b.r_y[l] = q.r[1]; b.r_z[l] = q.r[2];
+      b.v_x[l] = q.v[0]; b.v_y[l] = q.v[1]; b.v_z[l] = q.v[2];
+    }
+    return true;
   }
 
   // The MI355X path.  Observable effects are those of the reference's SimulateGPU()
@@ -505,6 +619,59 @@ class ParticleSimulation {
     }
   }
 
+  // One worker's share of a small step with 512-bit vectors (see SimulateAVX512).
+  NBODY_HOST_AVX512 void SmallStepAVX512(int worker, bool is_last_small_step) {
+    using V = nbody_host_detail::Vec512<float_t>;
+    using reg = typename V::reg;
+    constexpr int kRows = 4;  // i bodies per pass over the j bodies
+    int first, count;
+    nbody_host_detail::Share(num_particles_, num_threads_, worker, &first, &count);
+    const size_t padded = (static_cast<size_t>(num_particles_) + V::kLanes - 1) / V::kLanes * V::kLanes;
+    const float_t* x = soa_r_[scur_][0].data();
+    const float_t* y = soa_r_[scur_][1].data();
+    const float_t* z = soa_r_[scur_][2].data();
+    const float_t* m = soa_m_.data();
+    for (int i0 = first; i0 < first + count; i0 += kRows) {
+      const int rows = std::min(kRows, first + count - i0);
+      reg cx[kRows], cy[kRows], cz[kRows], ax[kRows], ay[kRows], az[kRows];
+      for (int k = 0; k < kRows; k++) {
+        const int i = i0 + std::min(k, rows - 1);  // a short last pass repeats its last body
+        cx[k] = V::Set1(x[i]); cy[k] = V::Set1(y[i]); cz[k] = V::Set1(z[i]);
+        ax[k] = ay[k] = az[k] = V::Set1(0);
+      }
+      for (size_t j = 0; j < padded; j += V::kLanes) {
+        const reg xj = V::Load(x + j), yj = V::Load(y + j), zj = V::Load(z + j), mj = V::Load(m + j);
+        for (int k = 0; k < kRows; k++) {
+          const reg dx = V::Sub(xj, cx[k]), dy = V::Sub(yj, cy[k]), dz = V::Sub(zj, cz[k]);
+          const reg r2 = V::Fma(dz, dz, V::Fma(dy, dy, V::Mul(dx, dx)));
+          const reg w = V::Weight(mj, r2);
+          ax[k] = V::Fma(w, dx, ax[k]);
+          ay[k] = V::Fma(w, dy, ay[k]);
+          az[k] = V::Fma(w, dz, az[k]);
+        }
+      }
+      for (int k = 0; k < rows; k++) {
+        const int i = i0 + k;
+        const float_t fa[3] = {G_ * V::Sum(ax[k]), G_ * V::Sum(ay[k]), G_ * V::Sum(az[k])};
+        for (int c = 0; c < 3; c++) {
+          const float_t v_old = soa_v_[c][i];
+          soa_v_[c][i] = v_old + (stepsize_ * fa[c]);
+          soa_r_[scur_ ^ 1][c][i] = soa_r_[scur_][c][i] + (stepsize_ * v_old);
+        }
+        if (is_last_small_step) {
+          OutPutParticle<float_t>& o = out_put_data_[current_big_step_][i];
+          for (int c = 0; c < 3; c++) {
+            o.r[c] = soa_r_[scur_ ^ 1][c][i];
+            o.v[c] = soa_v_[c][i];
+            o.a[c] = fa[c];
+          }
+          o.m = mass_[i];
+          o.t = stepsize_ * current_big_step_ * num_substeps_per_big_step_;
+        }
+      }
+    }
+  }
+
   // ref: particle_simulation.h:589-599
   void SaveFirstStep() {
     for (int i = 0; i < num_particles_; i++) {
@@ -574,6 +741,9 @@ class ParticleSimulation {
   std::vector<float_t> mass_;
   std::unique_ptr<Batch[]> batches_[2];
   std::unique_ptr<MassBatch[]> batch_mass_;
+  // SimulateAVX512(): plain coordinate runs, 64-byte aligned, padded to whole vectors
+  nbody_host_detail::AlignedArray<float_t> soa_r_[2][3], soa_v_[3], soa_m_;
+  int scur_ = 0;
   std::vector<std::vector<OutPutParticle<float_t>>> out_put_data_;
   std::vector<double> execution_time_;
   int64_t total_execution_time_ = 0;
