@@ -233,6 +233,14 @@ int nbody_mi355x_last_run_seconds(nbody_mi355x_sim* sim, double* seconds);
  * mass: double[n].  Units: G*M_total = 1 with the G passed in. */
 int nbody_mi355x_ic_plummer(int64_t n, uint64_t seed, double G, double* particles, double* mass);
 int nbody_mi355x_ic_uniform_cube(int64_t n, uint64_t seed, double G, double* particles, double* mass);
+/* A ring around a central body (body 0): the recipe of the reference's
+ * saturn_ring.cc:42-63 / NonCircularOrbitMoon (particle_initializer.h:120-175)
+ * for any n with the portable generator.  SI units; the
+ * reference's values: central_mass 5.683e26, ring_radius 1.12e8, width_sigma
+ * 3.0e7, thickness_sigma 50, v_sigma 50, mass_sigma 0.1. */
+int nbody_mi355x_ic_ring(int64_t n, uint64_t seed, double central_mass, double ring_radius,
+                         double width_sigma, double thickness_sigma, double v_sigma,
+                         double mass_sigma, double* particles, double* mass);
 
 #ifdef __cplusplus
 }

@@ -37,6 +37,11 @@ struct Rng {
     return r;
   }
   double u01() { return static_cast<double>(next() >> 11) * 0x1p-53; }  // [0,1)
+  double normal(double sigma) {  // Box-Muller, one deviate per call (two uniforms)
+    double u;
+    do { u = u01(); } while (u == 0.0);
+    return sigma * std::sqrt(-2.0 * std::log(u)) * std::cos(2.0 * M_PI * u01());
+  }
 };
 
 void isotropic(Rng& g, double len, double* out) {
@@ -99,6 +104,48 @@ extern "C" int nbody_mi355x_ic_uniform_cube(int64_t n, uint64_t seed, double G, 
     for (int k = 0; k < 3; k++) p[k] = 2.0 * g.u01() - 1.0;
     p[3] = p[4] = p[5] = 0.0;
     mass[i] = 1.0 / (G * static_cast<double>(n));
+  }
+  return NBODY_MI355X_OK;
+}
+
+// A ring around a central body: the recipe of the reference's saturn_ring.cc:42-63 for any
+// n, with this file's generator instead of libstdc++'s <random>.  Body 0 is the central
+// mass at rest at the origin; bodies 1..n-1 are built as the reference's
+// NonCircularOrbitMoon does (particle_initializer.h:120-175): at (radius, 0, dz) with
+// velocity (dvx, speed + dvy, 0), speed = sqrt(G_orbit * M / radius) with the initializer's
+// G_orbit = 6.67430e-11, then turned about Z by a uniform phase.  radius = ring_radius +
+// N(0, width_sigma), dz = N(0, thickness_sigma), dvx, dvy = N(0, v_sigma), mass =
+// N(0, mass_sigma)^2.
+extern "C" int nbody_mi355x_ic_ring(int64_t n, uint64_t seed, double central_mass, double ring_radius,
+                                    double width_sigma, double thickness_sigma, double v_sigma, double mass_sigma,
+                                    double* particles, double* mass) {
+  if (n <= 0 || !particles || !mass || !(central_mass > 0.0) || !(ring_radius > 0.0) || width_sigma < 0.0 ||
+      thickness_sigma < 0.0 || v_sigma < 0.0 || mass_sigma < 0.0) {
+    set_error("ic_ring: bad arguments");
+    return NBODY_MI355X_ERR_INVALID;
+  }
+  Rng g(seed);
+  const double G_orbit = 6.67430e-11;
+  for (int k = 0; k < 6; k++) particles[k] = 0.0;
+  mass[0] = central_mass;
+  for (int64_t i = 1; i < n; i++) {
+    const double dz = g.normal(thickness_sigma);
+    const double dvx = g.normal(v_sigma), dvy = g.normal(v_sigma);
+    const double phase = 2.0 * M_PI * g.u01();
+    const double ms = g.normal(mass_sigma);
+    double radius;
+    do { radius = ring_radius + g.normal(width_sigma); } while (!(radius > 0.0));
+    const double speed = std::sqrt(G_orbit * central_mass / radius);
+    const double c = std::cos(phase), s = std::sin(phase);
+    const double x = radius, y = 0.0, vx = dvx, vy = speed + dvy;
+    double* p = particles + 6 * i;
+    p[0] = x * c - y * s;
+    p[1] = x * s + y * c;
+    p[2] = dz;
+    p[3] = vx * c - vy * s;
+    p[4] = vx * s + vy * c;
+    p[5] = 0.0;
+    mass[i] = ms * ms;
   }
   return NBODY_MI355X_OK;
 }

@@ -125,3 +125,25 @@ inline std::vector<InPutParticle<double>> PlummerSphere(int64_t n, uint64_t seed
 inline std::vector<InPutParticle<double>> UniformCube(int64_t n, uint64_t seed = 7) {
   return SyntheticScene(false, n, seed);
 }
+
+// saturn_ring.cc's scene (ref: saturn_ring.cc:42-63) for any n, from the library's
+// portable generator: body 0 = the central mass, the rest on perturbed circular orbits.
+inline std::vector<InPutParticle<double>> Ring(int64_t n, uint64_t seed = 42, double central_mass = 5.683e+26,
+                                               double ring_radius = 1.12e+8, double width_sigma = 3.0e+7,
+                                               double thickness_sigma = 50, double v_sigma = 50,
+                                               double mass_sigma = 0.1) {
+  std::vector<double> p(6 * static_cast<size_t>(n)), m(static_cast<size_t>(n));
+  std::vector<InPutParticle<double>> out;
+  if (nbody_mi355x_ic_ring(n, seed, central_mass, ring_radius, width_sigma, thickness_sigma, v_sigma, mass_sigma,
+                           p.data(), m.data()) != NBODY_MI355X_OK)
+    return out;
+  out.resize(static_cast<size_t>(n));
+  for (size_t i = 0; i < out.size(); i++) {
+    for (int c = 0; c < 3; c++) {
+      out[i].particle.r[c] = p[6 * i + c];
+      out[i].particle.v[c] = p[6 * i + 3 + c];
+    }
+    out[i].m = m[i];
+  }
+  return out;
+}

@@ -90,6 +90,7 @@ SYMBOLS = {
     "nbody_mi355x_last_run_seconds": (C.c_int, [_P, C.POINTER(C.c_double)]),
     "nbody_mi355x_ic_plummer": (C.c_int, [C.c_int64, C.c_uint64, C.c_double, _P, _P]),
     "nbody_mi355x_ic_uniform_cube": (C.c_int, [C.c_int64, C.c_uint64, C.c_double, _P, _P]),
+    "nbody_mi355x_ic_ring": (C.c_int, [C.c_int64, C.c_uint64] + [C.c_double] * 6 + [_P, _P]),
 }
 
 _lib = None
@@ -180,6 +181,17 @@ class PinnedArray:
 
     def __exit__(self, *exc):
         self.close()
+
+
+def ic_ring(n: int, seed: int = 42, central_mass: float = 5.683e26, ring_radius: float = 1.12e8,
+            width_sigma: float = 3.0e7, thickness_sigma: float = 50.0, v_sigma: float = 50.0,
+            mass_sigma: float = 0.1):
+    """saturn_ring.cc's scene for any n (defaults: the reference's parameters)."""
+    p = np.empty((n, 6), dtype=np.float64)
+    m = np.empty(n, dtype=np.float64)
+    check(lib().nbody_mi355x_ic_ring(n, seed, central_mass, ring_radius, width_sigma, thickness_sigma, v_sigma,
+                                     mass_sigma, p.ctypes.data_as(_P), m.ctypes.data_as(_P)))
+    return p, m
 
 
 # ---------------------------------------------------------------- handle API

@@ -75,6 +75,32 @@ def test_ic_uniform_cube():
     assert np.allclose(m.sum() * nb.G_REFERENCE, 1.0)
 
 
+def test_ic_ring_follows_the_reference_recipe():
+    """saturn_ring.cc:42-63 at any n from the portable generator: central body at rest at
+    the origin, ring bodies near the ring plane on (perturbed) circular orbits about it with
+    the initializer's G = 6.67430e-11, radii ~ N(ring_radius, width), masses = N(0, .1)^2."""
+    n = 20000
+    p, m = nb.ic_ring(n, 42)
+    p2, m2 = nb.ic_ring(n, 42)
+    assert np.array_equal(p, p2) and np.array_equal(m, m2)
+    assert not np.array_equal(p, nb.ic_ring(n, 43)[0])
+    assert np.all(p[0] == 0) and m[0] == 5.683e26
+    r = np.hypot(p[1:, 0], p[1:, 1])
+    assert abs(r.mean() - 1.12e8) < 3 * 3.0e7 / np.sqrt(n) and abs(r.std() / 3.0e7 - 1) < 0.05
+    assert abs(p[1:, 2].std() / 50 - 1) < 0.05 and np.all(p[1:, 5] == 0)
+    phase = np.arctan2(p[1:, 1], p[1:, 0])
+    assert abs(phase.mean()) < 0.1 and abs(phase.std() - np.pi / np.sqrt(3)) < 0.05   # uniform in angle
+    # tangential speed = circular speed (+- 50 m/s), radial speed = +- 50 m/s
+    vt = (p[1:, 0] * p[1:, 4] - p[1:, 1] * p[1:, 3]) / r
+    vr = (p[1:, 0] * p[1:, 3] + p[1:, 1] * p[1:, 4]) / r
+    vc = np.sqrt(6.67430e-11 * 5.683e26 / r)
+    assert abs((vt - vc).std() / 50 - 1) < 0.05 and abs(vr.std() / 50 - 1) < 0.05
+    assert np.all(m[1:] >= 0) and abs(m[1:].mean() / 0.01 - 1) < 0.05   # E[N(0,.1)^2] = .01
+    with pytest.raises(nb.NBodyError):
+        nb.ic_ring(10, 1, central_mass=-1.0)
+
+
+
 @pytest.mark.parametrize("n,world", [(5, 3), (500, 8), (1048576, 8), (7, 8), (4194304, 8)])
 def test_shard_partition_matches_reference_threads(n, world):
     counts, begins = shard_counts(n, world)

@@ -376,3 +376,15 @@ def test_run_async_overlaps_and_matches_run(devices):
     for a, b in zip(ref, got):
         assert np.array_equal(a, b)
     assert np.array_equal(fin[:, :3], got[-1][:, :3])
+
+
+@pytest.mark.parametrize("n,variant", [(20000, 0), (3000, 0), (20000, 2)])
+def test_ring_scene_at_scale(n, variant):
+    """saturn_ring.cc's scene beyond N = 500 (nbody_mi355x_ic_ring): SI units, a mass ratio of
+    1e28 between body 0 and the ring, through the pair-symmetric and the one-sided kernels."""
+    p, m = nb.ic_ring(n, 42)
+    _, ref = ol.simulate(p, m, 1, 10, 0.01, threads=16)
+    _, out = gpu_simulate(p, m, 1, 10, 0.01, variant=variant)
+    assert rel_pos_err(out[0, 1:, :3], ref[0, 1:, :3]) <= 1e-14
+    assert np.abs(out[0, 0, :3] - ref[0, 0, :3]).max() <= 1e-12 * np.abs(ref[0, 0, :3]).max() + 1e-30
+    assert vec_rel(out[0, :, 6:9], ref[0, :, 6:9]) <= 1e-11
