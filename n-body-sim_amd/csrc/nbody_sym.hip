@@ -73,6 +73,7 @@ struct SymArgs {
   int r_first;         // first R chunk the finishing kernels add (0 = include the local phase's)
   int nR;              // one past the last R chunk they add
   int c_base;          // distance stored in row 0 of C for this batch
+  int no_eq;           // 1: never take the equal-mass form of the tile loop (tests)
   double eps2;
 };
 
@@ -151,7 +152,11 @@ constexpr int staged_groups() { return 4 * IPT < kStageGroups ? 4 * IPT : kStage
 // LDS entry with a return-less ds_add_f64 instead was tried: it removes the moves, but an
 // LDS atomic with 64-bit data holds up the SIMD's VALU issue for ~12 cycles, 3 of them cost
 // more than the 6 moves -- tools/ubench_lds.hip)
-template <int IPT, bool SYM, typename T>
+// EQ: every body of the row and of the staged groups has the same mass (checked per fill,
+// workgroup-uniform), so the two weights of a pair are the same number and one product
+// serves both sides: 19 instead of 20 FP64 operations per pair, bit-identical results.
+// The benchmark scenes (Plummer sphere, uniform cube) are equal-mass systems.
+template <int IPT, bool SYM, bool EQ, typename T>
 __device__ __forceinline__ void tile_phases(const P2<T>* xy, const P2<T>* zm, T (*fJ)[kGrp * staged_groups<IPT>()],
                                             int lane, int w, int ng, const T (&xi)[IPT], const T (&yi)[IPT],
                                             const T (&zi)[IPT], const T (&mi)[IPT], T (&ax)[IPT],
@@ -162,9 +167,11 @@ __device__ __forceinline__ void tile_phases(const P2<T>* xy, const P2<T>* zm, T 
     const int gb = grp * kGrp;
     T fx = 0, fy = 0, fz = 0;
     int rot = lane;  // at step t the lane meets body (lane + t) mod 64 of the group
-    // the body of the NEXT step is read while this step's pairs are evaluated
-    P2<T> jxy = xy[gb + rot];
-    P2<T> jzm = zm[gb + rot];
+    // the body of the NEXT step is read while this step's pairs are evaluated: two register
+    // sets used alternately (8 steps per trip: the roles are the same at every trip's start)
+    P2<T> bxy[2], bzm[2];
+    bxy[0] = xy[gb + rot];
+    bzm[0] = zm[gb + rot];
     for (int t8 = 0; t8 < 8; t8++) {
       const int rot_next = (rot + 8) & 63;
       const P2<T>* pxy = xy + gb + rot;
@@ -172,15 +179,18 @@ __device__ __forceinline__ void tile_phases(const P2<T>* xy, const P2<T>* zm, T 
 #pragma unroll
       for (int u = 0; u < 8; u++) {
         // (after the last step this reads the group's first body again: a valid address)
-        const P2<T> nxy = u < 7 ? pxy[u + 1] : xy[gb + rot_next];
-        const P2<T> nzm = u < 7 ? pzm[u + 1] : zm[gb + rot_next];
+        bxy[(u + 1) & 1] = u < 7 ? pxy[u + 1] : xy[gb + rot_next];
+        bzm[(u + 1) & 1] = u < 7 ? pzm[u + 1] : zm[gb + rot_next];
+        const P2<T> jxy = bxy[u & 1];
+        const P2<T> jzm = bzm[u & 1];
 #pragma unroll
         for (int k = 0; k < IPT; k++) {
           const T dx = jxy.a - xi[k];
           const T dy = jxy.b - yi[k];
           const T dz = jzm.a - zi[k];
           T si, sj = 0;
-          pair_weights<SYM>(dx, dy, dz, jzm.b, mi[k], eps2, c15, c1875, &si, &sj);
+          pair_weights<SYM && !EQ>(dx, dy, dz, jzm.b, mi[k], eps2, c15, c1875, &si, &sj);
+          if (EQ) sj = si;
           ax[k] = fma_t(si, dx, ax[k]);
           ay[k] = fma_t(si, dy, ay[k]);
           az[k] = fma_t(si, dz, az[k]);
@@ -195,8 +205,6 @@ __device__ __forceinline__ void tile_phases(const P2<T>* xy, const P2<T>* zm, T 
           fy = rotate_from_next_lane(fy);
           fz = rotate_from_next_lane(fz);
         }
-        jxy = nxy;
-        jzm = nzm;
       }
       rot = rot_next;
     }
@@ -252,6 +260,15 @@ __global__ __launch_bounds__(256) void sym_tiles_kernel(const SymArgs a) {
       ax[k] = ay[k] = az[k] = 0;
     }
   }
+  // do all bodies of this row have one mass?  (workgroup-uniform answer; NaN -> no)
+  __shared__ T m_row;
+  if (tid == 0) m_row = mi[0];
+  __syncthreads();
+  const T m_ref = m_row;
+  bool row_same = true;
+#pragma unroll
+  for (int k = 0; k < IPT; k++) row_same = row_same && (mi[k] == m_ref);
+  const bool row_uniform = __syncthreads_and(row_same) && !a.no_eq;
 
   // distances [d_lo, d_hi] cut into dsplit chunks whose sizes differ by at most one
   const int nd = a.d_hi - a.d_lo + 1;
@@ -272,11 +289,13 @@ __global__ __launch_bounds__(256) void sym_tiles_kernel(const SymArgs a) {
       const int j_lo = (g0 + c0) * 64, j_n = cg * 64;  // = bodies [j_lo, j_lo + j_n) of block J
 
       __syncthreads();  // every wave is done with the previous fill
+      bool fill_same = true;  // ... and do the staged bodies have that same mass?
       for (int o = tid; o < j_n; o += 256) {
         const int idx = j_lo + o;
         const int e = o & 63, q = (o >> 6) * kGrp + e;
         const P2<T> vxy{static_cast<T>(px[idx]), static_cast<T>(px[S + idx])};
         const P2<T> vzm{static_cast<T>(px[2 * S + idx]), static_cast<T>(pm[idx])};
+        fill_same = fill_same && (vzm.b == m_ref);
         xy[q] = vxy;
         zm[q] = vzm;
         fJ[0][q] = 0;
@@ -287,10 +306,13 @@ __global__ __launch_bounds__(256) void sym_tiles_kernel(const SymArgs a) {
           zm[q + 64] = vzm;
         }
       }
-      __syncthreads();
+      const bool equal_mass = __syncthreads_and(fill_same) && row_uniform;  // (also the barrier after the fill)
 
       if (sym) {
-        tile_phases<IPT, true, T>(xy, zm, fJ, lane, w, cg, xi, yi, zi, mi, ax, ay, az, eps2, c15, c1875);
+        if (equal_mass)
+          tile_phases<IPT, true, true, T>(xy, zm, fJ, lane, w, cg, xi, yi, zi, mi, ax, ay, az, eps2, c15, c1875);
+        else
+          tile_phases<IPT, true, false, T>(xy, zm, fJ, lane, w, cg, xi, yi, zi, mi, ax, ay, az, eps2, c15, c1875);
         for (int o = tid; o < j_n; o += 256) {
           const int idx = j_lo + o;
           const int q = (o >> 6) * kGrp + (o & 63);
@@ -299,7 +321,7 @@ __global__ __launch_bounds__(256) void sym_tiles_kernel(const SymArgs a) {
           Cd[2 * S + idx] = fJ[2][q];
         }
       } else {
-        tile_phases<IPT, false, T>(xy, zm, fJ, lane, w, cg, xi, yi, zi, mi, ax, ay, az, eps2, c15, c1875);
+        tile_phases<IPT, false, false, T>(xy, zm, fJ, lane, w, cg, xi, yi, zi, mi, ax, ay, az, eps2, c15, c1875);
       }
     }
   }
@@ -579,6 +601,8 @@ int sym_step(const nbody_mi355x_step_args& a, hipStream_t stream) {
   sa.d_lo = sa.d_hi = sa.r_base = 0;
   sa.c_base = 1;
   sa.eps2 = a.eps2;
+  const char* no_eq = getenv("NBODY_MI355X_SYM_NOEQ");  // tests: compare the two forms bit for bit
+  sa.no_eq = (no_eq && atoi(no_eq) != 0) ? 1 : 0;
   const int b = static_cast<int>(batch);
   hipError_t e;
   if (a.precision == NBODY_MI355X_FP32) {

@@ -388,3 +388,18 @@ def test_ring_scene_at_scale(n, variant):
     assert rel_pos_err(out[0, 1:, :3], ref[0, 1:, :3]) <= 1e-14
     assert np.abs(out[0, 0, :3] - ref[0, 0, :3]).max() <= 1e-12 * np.abs(ref[0, 0, :3]).max() + 1e-30
     assert vec_rel(out[0, :, 6:9], ref[0, :, 6:9]) <= 1e-11
+
+
+@pytest.mark.parametrize("precision", ["fp64", "fp32"])
+def test_equal_mass_form_is_bit_identical(precision, monkeypatch):
+    """The pair-symmetric tile loop has a form for fills whose bodies all have the row's mass
+    (one weight product serves both sides of a pair).  It must not change a single bit
+    against the general form, on an equal-mass scene (where it is taken for every full tile)
+    and it must not be taken where masses differ (ring scene: same results either way)."""
+    prec = nb.FP64 if precision == "fp64" else nb.FP32
+    for p, m, dt in [nb.ic_plummer(20000, 5) + (1e-3,), nb.ic_ring(9000, 3) + (0.01,)]:
+        monkeypatch.delenv("NBODY_MI355X_SYM_NOEQ", raising=False)
+        fin_a, a = gpu_simulate(p, m, 1, 5, dt, precision=prec)
+        monkeypatch.setenv("NBODY_MI355X_SYM_NOEQ", "1")
+        fin_b, b = gpu_simulate(p, m, 1, 5, dt, precision=prec)
+        assert np.array_equal(a, b) and np.array_equal(fin_a, fin_b)
