@@ -73,7 +73,7 @@ struct SymArgs {
   int r_first;         // first R chunk the finishing kernels add (0 = include the local phase's)
   int nR;              // one past the last R chunk they add
   int c_base;          // distance stored in row 0 of C for this batch
-  int no_eq;           // 1: never take the equal-mass form of the tile loop (tests)
+  int no_eq;           // 1: never take the equal-mass forms of the tile loop (tests)
   double eps2;
 };
 
@@ -107,9 +107,7 @@ __device__ __forceinline__ float fma_t(float a, float b, float c) { return __bui
 // float (the FP32 variant): v_rsq_f32 is good to an ulp; r^2 == 0 is an explicit select
 // because 2^-600 does not exist in float; and the mass is multiplied in BEFORE the cube is
 // completed, (m y0) (y0 y0), so that r^-3 alone never underflows (r = 1e13 m: 1e-39).
-template <bool WANT_J>
-__device__ __forceinline__ void pair_weights(double dx, double dy, double dz, double mj, double mi, double eps2,
-                                             double c15, double c1875, double* si, double* sj) {
+__device__ __forceinline__ double pair_r3(double dx, double dy, double dz, double eps2, double c15, double c1875) {
   const double r2 = __builtin_fma(dz, dz, __builtin_fma(dy, dy, __builtin_fma(dx, dx, eps2)));
   const double y0 = __builtin_amdgcn_rsq(r2);
   const double u = y0 * y0;
@@ -117,7 +115,13 @@ __device__ __forceinline__ void pair_weights(double dx, double dy, double dz, do
   const double w0 = y0 * u;
   const double p = __builtin_fma(e, c1875, c15);
   const double we = w0 * e;
-  const double s0 = __builtin_fma(we, p, w0);  // r^-3
+  return __builtin_fma(we, p, w0);  // r^-3
+}
+__device__ __forceinline__ float pair_r3(float, float, float, float, float, float) { return 0.0f; }  // (double only)
+template <bool WANT_J>
+__device__ __forceinline__ void pair_weights(double dx, double dy, double dz, double mj, double mi, double eps2,
+                                             double c15, double c1875, double* si, double* sj) {
+  const double s0 = pair_r3(dx, dy, dz, eps2, c15, c1875);
   *si = s0 * mj;
   if (WANT_J) *sj = s0 * mi;
 }
@@ -152,15 +156,27 @@ constexpr int staged_groups() { return 4 * IPT < kStageGroups ? 4 * IPT : kStage
 // LDS entry with a return-less ds_add_f64 instead was tried: it removes the moves, but an
 // LDS atomic with 64-bit data holds up the SIMD's VALU issue for ~12 cycles, 3 of them cost
 // more than the 6 moves -- tools/ubench_lds.hip)
-// EQ: every body of the row and of the staged groups has the same mass (checked per fill,
-// workgroup-uniform), so the two weights of a pair are the same number and one product
-// serves both sides: 19 instead of 20 FP64 operations per pair, bit-identical results.
-// The benchmark scenes (Plummer sphere, uniform cube) are equal-mass systems.
-template <int IPT, bool SYM, bool EQ, typename T>
+// MODE selects how the masses enter (workgroup-uniform, chosen per LDS fill):
+//   kGeneral   si = m_j r^-3, sj = m_i r^-3: 20 FP64 operations per pair.
+//   kDeferred  (double) every body of the row AND of the staged groups has the one mass
+//              m_ref: both sides take the bare r^-3 and the mass is multiplied in once per
+//              sum instead of once per pair -- the j sums when a wave adds them to LDS, the
+//              i sums (which stay in units of 1/m_ref for the whole row) when the row is
+//              stored: 18 operations per pair.  The benchmark scenes (Plummer sphere,
+//              uniform cube) are equal-mass systems, and so are all but one row of a ring.
+//   kRowUnit   (double) the row has one mass but the staged bodies do not (a padded block,
+//              the ring's planet): the i sums are in units of 1/m_ref, so the i-side weight
+//              is (m_j r^-3) / m_ref; j side as kGeneral.  Rare; 21 operations.
+//   kSameMass  (float) as kDeferred's condition, but the mass stays in the product (r^-3
+//              alone can leave float's range) and one product serves both sides: 19.
+// kDeferred / kRowUnit round once more per sum than kGeneral (the final product with m_ref):
+// results agree to an ulp or two of each sum, not bit for bit.
+enum { kGeneral = 0, kDeferred = 1, kRowUnit = 2, kSameMass = 3 };
+template <int IPT, bool SYM, int MODE, typename T>
 __device__ __forceinline__ void tile_phases(const P2<T>* xy, const P2<T>* zm, T (*fJ)[kGrp * staged_groups<IPT>()],
                                             int lane, int w, int ng, const T (&xi)[IPT], const T (&yi)[IPT],
                                             const T (&zi)[IPT], const T (&mi)[IPT], T (&ax)[IPT],
-                                            T (&ay)[IPT], T (&az)[IPT], T eps2, T c15, T c1875) {
+                                            T (&ay)[IPT], T (&az)[IPT], T eps2, T c15, T c1875, T m_ref, T inv_m_ref) {
   // the staged groups 0 .. ng-1 (ng a multiple of 4)
   for (int ph = 0; ph < ng; ph++) {
     const int grp = (ph + (ng >> 2) * w) % ng;  // the 4 waves sit on 4 different groups
@@ -189,8 +205,17 @@ __device__ __forceinline__ void tile_phases(const P2<T>* xy, const P2<T>* zm, T 
           const T dy = jxy.b - yi[k];
           const T dz = jzm.a - zi[k];
           T si, sj = 0;
-          pair_weights<SYM && !EQ>(dx, dy, dz, jzm.b, mi[k], eps2, c15, c1875, &si, &sj);
-          if (EQ) sj = si;
+          if constexpr (MODE == kDeferred) {
+            si = sj = pair_r3(dx, dy, dz, eps2, c15, c1875);
+          } else if constexpr (MODE == kRowUnit) {
+            pair_weights<SYM>(dx, dy, dz, jzm.b, mi[k], eps2, c15, c1875, &si, &sj);
+            si *= inv_m_ref;
+          } else if constexpr (MODE == kSameMass) {
+            pair_weights<false>(dx, dy, dz, jzm.b, mi[k], eps2, c15, c1875, &si, &sj);
+            sj = si;
+          } else {
+            pair_weights<SYM>(dx, dy, dz, jzm.b, mi[k], eps2, c15, c1875, &si, &sj);
+          }
           ax[k] = fma_t(si, dx, ax[k]);
           ay[k] = fma_t(si, dy, ay[k]);
           az[k] = fma_t(si, dz, az[k]);
@@ -209,6 +234,11 @@ __device__ __forceinline__ void tile_phases(const P2<T>* xy, const P2<T>* zm, T 
       rot = rot_next;
     }
     if (SYM) {  // 64 rotations later the sums are home: lane l holds body l of the group
+      if constexpr (MODE == kDeferred) {
+        fx *= m_ref;
+        fy *= m_ref;
+        fz *= m_ref;
+      }
       fJ[0][gb + lane] += fx;
       fJ[1][gb + lane] += fy;
       fJ[2][gb + lane] += fz;
@@ -260,15 +290,18 @@ __global__ __launch_bounds__(256) void sym_tiles_kernel(const SymArgs a) {
       ax[k] = ay[k] = az[k] = 0;
     }
   }
-  // do all bodies of this row have one mass?  (workgroup-uniform answer; NaN -> no)
+  // do all bodies of this row have one (finite, non-zero) mass?  Workgroup-uniform answer.
   __shared__ T m_row;
   if (tid == 0) m_row = mi[0];
   __syncthreads();
   const T m_ref = m_row;
-  bool row_same = true;
+  bool row_same = (m_ref != 0) && (m_ref - m_ref == 0);  // not 0, inf or NaN
 #pragma unroll
   for (int k = 0; k < IPT; k++) row_same = row_same && (mi[k] == m_ref);
   const bool row_uniform = __syncthreads_and(row_same) && !a.no_eq;
+  // double: a uniform row keeps its i sums in units of 1/m_ref (kDeferred / kRowUnit)
+  constexpr bool kDouble = sizeof(T) == sizeof(double);
+  const T inv_m_ref = row_uniform ? 1 / m_ref : 0;
 
   // distances [d_lo, d_hi] cut into dsplit chunks whose sizes differ by at most one
   const int nd = a.d_hi - a.d_lo + 1;
@@ -308,11 +341,17 @@ __global__ __launch_bounds__(256) void sym_tiles_kernel(const SymArgs a) {
       }
       const bool equal_mass = __syncthreads_and(fill_same) && row_uniform;  // (also the barrier after the fill)
 
+#define NBODY_TILE(SYM_, MODE_) \
+  tile_phases<IPT, SYM_, MODE_, T>(xy, zm, fJ, lane, w, cg, xi, yi, zi, mi, ax, ay, az, eps2, c15, c1875, m_ref, inv_m_ref)
       if (sym) {
-        if (equal_mass)
-          tile_phases<IPT, true, true, T>(xy, zm, fJ, lane, w, cg, xi, yi, zi, mi, ax, ay, az, eps2, c15, c1875);
-        else
-          tile_phases<IPT, true, false, T>(xy, zm, fJ, lane, w, cg, xi, yi, zi, mi, ax, ay, az, eps2, c15, c1875);
+        if (kDouble) {
+          if (equal_mass) NBODY_TILE(true, kDeferred);
+          else if (row_uniform) NBODY_TILE(true, kRowUnit);
+          else NBODY_TILE(true, kGeneral);
+        } else {
+          if (equal_mass) NBODY_TILE(true, kSameMass);
+          else NBODY_TILE(true, kGeneral);
+        }
         for (int o = tid; o < j_n; o += 256) {
           const int idx = j_lo + o;
           const int q = (o >> 6) * kGrp + (o & 63);
@@ -320,9 +359,11 @@ __global__ __launch_bounds__(256) void sym_tiles_kernel(const SymArgs a) {
           Cd[S + idx] = fJ[1][q];
           Cd[2 * S + idx] = fJ[2][q];
         }
-      } else {
-        tile_phases<IPT, false, false, T>(xy, zm, fJ, lane, w, cg, xi, yi, zi, mi, ax, ay, az, eps2, c15, c1875);
+      } else {  // the diagonal tile (1 of nb/2 + 1): no form of its own for equal masses
+        if (kDouble && row_uniform) NBODY_TILE(false, kRowUnit);
+        else NBODY_TILE(false, kGeneral);
       }
+#undef NBODY_TILE
     }
   }
 
@@ -331,6 +372,11 @@ __global__ __launch_bounds__(256) void sym_tiles_kernel(const SymArgs a) {
 #pragma unroll
   for (int k = 0; k < IPT; k++) {
     const int idx = k * 256 + tid;
+    if (kDouble && row_uniform) {  // back from units of 1/m_ref
+      ax[k] *= m_ref;
+      ay[k] *= m_ref;
+      az[k] *= m_ref;
+    }
     Rs[idx] = ax[k];
     Rs[S + idx] = ay[k];
     Rs[2 * S + idx] = az[k];
