@@ -76,7 +76,16 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
     ap.add_argument("--share-devices", action="store_true",
                     help="rehearsal only: ranks share the visible GPUs (device = local_rank %% device_count)")
+    ap.add_argument("--force-collectives", action="store_true",
+                    help="rehearsal only: with one rank, still take the multi-rank code path (RCCL "
+                         "all-gather + reduce-scatter over a world of 1, split steps)")
     args = ap.parse_args()
+
+    # stdout carries ONE JSON line: libraries that print banners there (RCCL prints its
+    # version on the first communicator) are sent to stderr until the line is written
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
 
     import torch
     import torch.distributed as dist
@@ -96,8 +105,10 @@ def main():
     dev_index = local_rank % torch.cuda.device_count() if args.share_devices else local_rank
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
-    if world > 1:
+    use_dist = world > 1 or args.force_collectives
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         else:
@@ -108,12 +119,12 @@ def main():
     p, m = nb.ic_plummer(n, 42)                       # same ICs on every rank
     sim = ShardedNBody(p, m, 1e-3, rank=rank, world=world, device=device,
                        backend=HipBackend(precision=prec, variant=args.variant),
-                       overlap=not args.no_overlap)
+                       overlap=not args.no_overlap, force_collectives=args.force_collectives)
     del p, m
 
     def barrier():
         torch.cuda.synchronize(device)
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize(device)
 
@@ -171,9 +182,12 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
         print(json.dumps(line), flush=True)
+        os.dup2(2, 1)
 
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -68,7 +68,8 @@ struct SymArgs {
   int D;               // largest distance = nb / 2
   int d_lo, d_hi;      // distances this launch covers, inclusive
   int dsplit;          // chunks [d_lo, d_hi] is cut into (grid.y)
-  int jsplit;          // parts a tile's j groups are cut into (grid.z): 1, 2 or 4, <= IPT
+  int jsplit;          // parts a tile's j groups are cut into (grid.z): 1, 2, 4 or 8, <= IPT
+  int jlocal;          // the same for the launch of phase 1 (diagonal tiles only); host side only
   int r_base;          // R chunk of this launch's chunk 0
   int r_first;         // first R chunk the finishing kernels add (0 = include the local phase's)
   int nR;              // one past the last R chunk they add
@@ -462,7 +463,7 @@ __global__ __launch_bounds__(256) void sym_integrate_kernel(const double* __rest
 }
 
 struct Plan {
-  int ipt, nbs, nb, D, dsplit, jsplit;
+  int ipt, nbs, nb, D, dsplit, jsplit, jlocal;
   int64_t bytes;      // preferred workspace: every distance in one batch, capped (kBatchCap)
   int64_t row_bytes;  // 3 * S doubles: one R chunk / one distance of C / the batch accumulator
 };
@@ -471,10 +472,10 @@ struct Plan {
 // of one batch would otherwise grow as N^2 / block: 206 GB at N = 4M on one GPU).
 constexpr int64_t kBatchCap = int64_t{16} << 30;
 
-// rows of the workspace that are not C: R chunks (1 local + ds) and, on one slab, the
-// accumulator that batches add into
+// rows of the workspace that are not C: R chunks (jlocal of phase 1 + ds * js) and, on one
+// slab, the accumulator that batches add into
 int64_t fixed_rows(const Plan& p, int num_shards) {
-  return 1 + static_cast<int64_t>(p.dsplit) * p.jsplit + (num_shards == 1 ? 1 : 0);
+  return p.jlocal + static_cast<int64_t>(p.dsplit) * p.jsplit + (num_shards == 1 ? 1 : 0);
 }
 
 // One candidate block size: fills *p and returns its modelled time (arbitrary units), or a
@@ -514,6 +515,13 @@ double plan_for(const nbody_mi355x_step_args& a, int ipt, Plan* p) {
     if ((v == 1 || v == 2 || v == 4 || v == 8) && v <= ipt) js = v;
   }
   p->jsplit = js;
+  // phase 1 (multi-rank runs: the diagonal tiles, while the all-gather is in flight) has one
+  // tile per own row: with few rows per rank the tiles are split so that the launch still
+  // puts two workgroups on every CU (8 ranks at N = 1M: 64 rows -> 512 workgroups of 1/8 tile;
+  // unsplit, that launch ran 64 workgroups for a whole tile's time: +0.6 ms per step)
+  int jl = 1;
+  while (jl < ipt && static_cast<int64_t>(p->nbs) * jl < 2 * 256) jl *= 2;
+  p->jlocal = a.num_shards > 1 ? jl : 1;
   const double tile = static_cast<double>(B) * static_cast<double>(B) * pair_cost;
   const double best = static_cast<double>(p->nbs) * nd * tile / 256.0 + tile / js * per_cu;
   p->row_bytes = static_cast<int64_t>(sizeof(double)) * 3 * a.shard_slots;
@@ -550,12 +558,12 @@ hipError_t launch(SymArgs sa, const nbody_mi355x_step_args& a, hipStream_t strea
   // phase 1 = what needs the own slab only (the diagonal tiles), kept in R[0];
   // phase 2 = the rest, then output; phase 0 = both
   if (a.phase == 1) {
-    sa.d_lo = 0; sa.d_hi = 0; sa.dsplit = 1; sa.jsplit = 1; sa.r_base = 0; sa.c_base = 1;
-    hipLaunchKernelGGL((sym_tiles_kernel<IPT, T>), dim3(sa.nbs, 1, 1), dim3(256), 0, stream, sa);
+    sa.d_lo = 0; sa.d_hi = 0; sa.dsplit = 1; sa.jsplit = sa.jlocal; sa.r_base = 0; sa.c_base = 1;
+    hipLaunchKernelGGL((sym_tiles_kernel<IPT, T>), dim3(sa.nbs, 1, sa.jlocal), dim3(256), 0, stream, sa);
     return hipGetLastError();
   }
   const int d_first = a.phase == 2 ? 1 : 0;
-  sa.r_base = 1;
+  sa.r_base = sa.jlocal;
   double* out = a.acc_out != nullptr ? a.acc_out : accum;
   for (int lo = d_first, hi; lo <= sa.D; lo = hi + 1) {
     // `batch` rows of C hold the distances max(lo,1) .. hi (d = 0 needs none)
@@ -565,7 +573,7 @@ hipError_t launch(SymArgs sa, const nbody_mi355x_step_args& a, hipStream_t strea
     sa.d_lo = lo;
     sa.d_hi = hi;
     sa.c_base = lo > 1 ? lo : 1;
-    sa.r_first = (first && a.phase == 2) ? 0 : 1;  // the local phase's chunk joins the first batch
+    sa.r_first = (first && a.phase == 2) ? 0 : sa.jlocal;  // the local phase's chunks join the first batch
     hipLaunchKernelGGL((sym_tiles_kernel<IPT, T>), dim3(sa.nbs, sa.dsplit, sa.jsplit), dim3(256), 0, stream, sa);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
@@ -633,7 +641,7 @@ int sym_step(const nbody_mi355x_step_args& a, hipStream_t stream) {
   sa.pos = a.pos_cur;
   sa.mass = a.mass;
   sa.R = static_cast<double*>(a.workspace);
-  sa.C = sa.R + static_cast<int64_t>(1 + p.dsplit * p.jsplit) * 3 * a.shard_slots;
+  sa.C = sa.R + static_cast<int64_t>(p.jlocal + p.dsplit * p.jsplit) * 3 * a.shard_slots;
   double* accum = a.num_shards == 1 ? sa.C + batch * 3 * a.shard_slots : nullptr;
   sa.S = a.shard_slots;
   sa.nbs = p.nbs;
@@ -642,8 +650,9 @@ int sym_step(const nbody_mi355x_step_args& a, hipStream_t stream) {
   sa.D = p.D;
   sa.dsplit = p.dsplit;
   sa.jsplit = p.jsplit;
-  sa.r_first = 1;
-  sa.nR = 1 + p.dsplit * p.jsplit;
+  sa.jlocal = p.jlocal;
+  sa.r_first = p.jlocal;
+  sa.nR = p.jlocal + p.dsplit * p.jsplit;
   sa.d_lo = sa.d_hi = sa.r_base = 0;
   sa.c_base = 1;
   sa.eps2 = a.eps2;

@@ -83,12 +83,15 @@ class HipBackend:
 
 class ShardedNBody:
     def __init__(self, particles, mass, dt, *, rank=0, world=1, device="cuda", G=G_REFERENCE, eps2=0.0,
-                 backend=None, overlap=True, group=None, use_workspace=True):
+                 backend=None, overlap=True, group=None, use_workspace=True, force_collectives=False):
         particles = np.ascontiguousarray(particles, dtype=np.float64).reshape(-1, 6)
         mass = np.ascontiguousarray(mass, dtype=np.float64)
         self.n, self.rank, self.world = particles.shape[0], rank, world
         self.dt, self.G, self.eps2 = float(dt), float(G), float(eps2)
         self.overlap, self.group = overlap, group
+        # rehearsal: take the multi-rank code path (collectives, split steps, partial-sum
+        # exchange) even with one rank, so that RCCL itself can be exercised on a one-GPU box
+        self.multi = world > 1 or force_collectives
         self.device = torch.device(device)
         self.backend = backend if backend is not None else HipBackend()
         self.counts, self.begins = shard_counts(self.n, world)
@@ -126,7 +129,7 @@ class ShardedNBody:
             free_b, _ = torch.cuda.mem_get_info(self.device)
             if 0 < need < free_b // 2:
                 self.workspace = torch.empty(need // 8, dtype=torch.float64, device=dev)
-                if world > 1:
+                if self.multi:
                     self.acc_all = torch.zeros((world, 3, S), dtype=torch.float64, device=dev)
         self.sym_variant = variant if variant in SYM_VARIANTS else VARIANT_SYM
         self._send = None
@@ -140,7 +143,7 @@ class ShardedNBody:
         common = dict(pos_cur=cur, pos_next=nxt, mass=self.mass, vel=self.vel, S=S, world=P, rank=r,
                       count=self.count, dt=self.dt, G=self.G, eps2=self.eps2)
         snap = self.snap if snapshot else None
-        if P == 1:
+        if not self.multi:
             extra = {"workspace": self.workspace} if self.workspace is not None else {}
             self.backend.step(acc_in=None, acc_out=None, snapshot=snap, ranges=((0, self.n), (0, 0)), **common, **extra)
         elif self.workspace is not None:
@@ -216,7 +219,7 @@ class ShardedNBody:
 
     def sync_positions(self):
         """Make every slab of the current buffer current (needed before reading remote slabs)."""
-        if self.world > 1 and not self._fresh:
+        if self.multi and not self._fresh:
             self._all_gather(self.pos[self.cur], async_op=False)
             self._fresh = True
 

@@ -195,6 +195,64 @@ def test_two_real_ranks_end_to_end(n, expect_sym):
     assert (num / np.linalg.norm(out[0, :, 6:9], axis=1)).max() <= 1e-12
 
 
+def _rccl_single_rank_main(port, n, steps, q):
+    """One rank, backend nccl (= RCCL), forced through the multi-rank code path."""
+    import os
+    import sys
+    from pathlib import Path
+    repo = Path(__file__).resolve().parent.parent
+    sys.path.insert(0, str(repo / "n-body-sim_amd"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        import nbody_mi355x as nb
+        from nbody_mi355x.sharded import ShardedNBody
+        p, m = nb.ic_plummer(n, 31)
+        sim = ShardedNBody(p, m, 1e-3, rank=0, world=1, device="cuda:0", overlap=True, force_collectives=True)
+        for k in range(steps):
+            sim.step(snapshot=(k == steps - 1))
+        torch.cuda.synchronize()
+        pos = sim.all_positions()
+        q.put((sim.own_state(), sim.own_snapshot(), sim.workspace is not None, pos))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n,expect_sym", [(1500, False), (20000, True)])
+def test_rccl_collectives_single_rank(n, expect_sym):
+    """The collectives bench.py issues on an 8-GPU node -- all_gather_into_tensor of the own slab
+    (asynchronous, overlapped with the own-slab part, work.wait() before the rest) and
+    reduce_scatter_tensor of the pair-symmetric partial sums -- through RCCL itself, with the
+    one rank a one-GPU box allows: same calls, same buffers and stream ordering, result
+    against the oracle."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    steps = 5
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    pr = ctx.Process(target=_rccl_single_rank_main, args=(port, n, steps, q))
+    pr.start()
+    state, snap, used_sym, pos = q.get(timeout=150)
+    pr.join(timeout=60)
+    assert pr.exitcode == 0
+    assert used_sym == expect_sym
+    p, m = nb.ic_plummer(n, 31)
+    fin, out = ol.simulate(p, m, 1, steps, 1e-3, threads=16)
+    assert rel_pos_err(state[:, :3], fin[:, :3]) <= 1e-13
+    assert rel_pos_err(pos, fin[:, :3]) <= 1e-13
+    assert rel_pos_err(snap[:, :3], out[0, :, :3]) <= 1e-13
+    num = np.linalg.norm(snap[:, 6:9] - out[0, :, 6:9], axis=1)
+    assert (num / np.linalg.norm(out[0, :, 6:9], axis=1)).max() <= 1e-12
+
+
 @pytest.mark.parametrize("world,n,drop", [(1, 20000, 1), (1, 20000, 7), (2, 30000, 5), (1, 5000, 3)])
 def test_symmetric_distance_batching(world, n, drop):
     """A workspace too small for every distance at once: the symmetric kernels work through
