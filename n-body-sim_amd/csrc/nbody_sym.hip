@@ -500,7 +500,8 @@ double plan_for(const nbody_mi355x_step_args& a, int ipt, Plan* p) {
   // 6 DPP moves per IPT pairs on top of 96 cycles of FP64 work per pair
   const double pair_cost = ipt == 8 ? 0.97 : (ipt == 4 ? 1.00 : (ipt == 2 ? 1.05 : 1.15));
   const int nd = p->D + 1;
-  int ds = nd < 32 ? nd : 32;
+  const int ds_cap = ipt == 8 ? 32 : 16;  // (measured: smaller blocks gain nothing beyond 16)
+  int ds = nd < ds_cap ? nd : ds_cap;
   if (const char* env = getenv("NBODY_MI355X_SYM_DSPLIT")) {  // tuning experiments only
     const int v = atoi(env);
     if (v > 0) ds = v;
@@ -509,7 +510,7 @@ double plan_for(const nbody_mi355x_step_args& a, int ipt, Plan* p) {
   if (ds < 1) ds = 1;
   p->dsplit = ds;
   int js = 1;
-  while (js < ipt && static_cast<int64_t>(p->nbs) * nd * js < 32 * 256) js *= 2;
+  while (js < ipt && static_cast<int64_t>(p->nbs) * nd * js < 64 * 256) js *= 2;
   if (const char* env = getenv("NBODY_MI355X_SYM_JSPLIT")) {  // tuning experiments only
     const int v = atoi(env);
     if ((v == 1 || v == 2 || v == 4 || v == 8) && v <= ipt) js = v;
@@ -538,18 +539,26 @@ bool make_plan(const nbody_mi355x_step_args& a, Plan* p) {
   if (a.variant == NBODY_MI355X_VARIANT_SYM2) return plan_for(a, 2, p) >= 0.0;
   if (a.variant == NBODY_MI355X_VARIANT_SYM4) return plan_for(a, 4, p) >= 0.0;
   if (a.variant == NBODY_MI355X_VARIANT_SYM8) return plan_for(a, 8, p) >= 0.0;
-  // automatic: the fastest block size by the model whose workspace stays moderate
-  // (it grows as N^2 / block; the largest block is always allowed)
-  const int64_t cap = int64_t{16} << 30;
-  bool found = false;
-  double best = 0.0;
+  // automatic: the largest block that still leaves enough tiles per rank to keep 512
+  // resident workgroups busy to the end.  Bigger blocks cost fewer DPP moves per pair, but
+  // a launch of few big tiles is mostly ramp and tail.  Thresholds from sweeps on MI355X
+  // (Ginteractions/s, best block per size): 16 384 bodies: 256-body blocks 1665 (1024: 1326);
+  // 32 768: 512 2371 (2048: 2264); 65 536: 1024 2802 (2048: 2744); 131 072: 1024 2880
+  // (2048: 2783); 262 144 and up: 2048.  The model value of plan_for only breaks ties.
   for (int ipt : {8, 4, 2, 1}) {
     Plan c;
-    const double t = plan_for(a, ipt, &c);
-    if (t < 0.0 || (ipt < 4 && c.bytes > cap)) continue;
-    if (!found || t < best) { found = true; best = t; *p = c; }
+    if (plan_for(a, ipt, &c) < 0.0) continue;
+    const int64_t tiles = static_cast<int64_t>(c.nbs) * (c.D + 1);
+    if (ipt > 1 && tiles < (ipt == 8 ? 8192 : 2048)) {
+      Plan smaller;  // only if a smaller block applies at all (shard_slots divisible, >= 2 blocks)
+      bool any = false;
+      for (int q = ipt / 2; q >= 1 && !any; q /= 2) any = plan_for(a, q, &smaller) >= 0.0;
+      if (any) continue;
+    }
+    *p = c;
+    return true;
   }
-  return found;
+  return false;
 }
 
 template <int IPT, typename T>
