@@ -14,6 +14,12 @@
 //   nbody_host_cli demo   NAME PATH [BIG] [SUB_DIVISOR] [OUTDIR]
 //       run a reference scene with its own step parameters (SUB divided by SUB_DIVISOR to
 //       shorten it) and write the text files the reference writes
+//   nbody_host_cli bench  IC N PATH [BIG] [SUB] [THREADS]
+//       IC = plummer | cube | ring (the library's portable generators, seed 42 / 7 / 42);
+//       BIG big steps (default 3) of SUB small steps (default 5) through ParticleSimulation
+//       and the chosen Simulate path; one JSON line: Ginteractions/s from the host's own
+//       wall clock around every big step after the first (which holds the set-up), i.e.
+//       what a user of SimulateMI355X() sees, snapshot copy and unpack included
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -192,6 +198,40 @@ int main(int argc, char** argv) {
     std::cout << status << std::endl;
     if (s.per_timestep_files) my_sim.WriteTimestepFiles(dir); else my_sim.WriteParticleFiles(dir);
     my_sim.PrintAverageStepTime();
+    return 0;
+  }
+  if (cmd == "bench" && argc >= 5) {
+    const std::string ic = argv[2], path = argv[4];
+    const int64_t n = atoll(argv[3]);
+    const int64_t big = argc > 5 ? atoll(argv[5]) : 3, sub = argc > 6 ? atoll(argv[6]) : 5;
+    const int threads = argc > 7 ? atoi(argv[7]) : static_cast<int>(std::thread::hardware_concurrency());
+    if (n < 1 || n >= (int64_t{1} << 31) || big < 2 || sub < 1) { fprintf(stderr, "bench: N >= 1, BIG >= 2, SUB >= 1\n"); return 2; }
+    std::vector<double> p(6 * static_cast<size_t>(n)), m(static_cast<size_t>(n));
+    const double G = 6.7430e-11;  // the simulator's constant (ref: particle_simulation.h:713)
+    double dt = 1e-3;
+    int rc;
+    if (ic == "plummer") rc = nbody_mi355x_ic_plummer(n, 42, G, p.data(), m.data());
+    else if (ic == "cube") { rc = nbody_mi355x_ic_uniform_cube(n, 7, G, p.data(), m.data()); dt = 1e-4; }
+    else if (ic == "ring") { rc = nbody_mi355x_ic_ring(n, 42, 5.683e+26, 1.12e+8, 3.0e+7, 50, 50, 0.1, p.data(), m.data()); dt = 0.01; }
+    else { fprintf(stderr, "unknown IC %s\n", ic.c_str()); return 2; }
+    if (rc != NBODY_MI355X_OK) { fprintf(stderr, "%s\n", nbody_mi355x_last_error()); return 3; }
+    ParticleSimulation<double, 4> sim(static_cast<int>(n), big, sub, dt, threads);
+    sim.SetQuiet(true);
+    for (int64_t i = 0; i < n; i++) {
+      Particle<double> q;
+      for (int c = 0; c < 3; c++) { q.r[c] = p[6 * i + c]; q.v[c] = p[6 * i + 3 + c]; }
+      sim.SetParticle(q, m[i]);
+    }
+    sim.SetMissingParticlesInBatch();
+    const std::string status = Simulate(sim, path);
+    fprintf(stderr, "%s\n", status.c_str());
+    if (status != "ok" && status.find("succesfull") == std::string::npos) return 3;
+    double sec = 0;
+    for (int64_t k = 1; k < big; k++) sec += sim.BigStepSeconds()[k];
+    const double inter = static_cast<double>(n) * static_cast<double>(n) * static_cast<double>(sub) * static_cast<double>(big - 1);
+    printf("{\"ic\": \"%s\", \"bodies\": %lld, \"path\": \"%s\", \"big_steps_timed\": %lld, \"substeps\": %lld, "
+           "\"threads\": %d, \"seconds\": %.6f, \"Ginteractions_per_s\": %.2f, \"clock\": \"host wall clock per big step\"}\n",
+           ic.c_str(), (long long)n, path.c_str(), (long long)(big - 1), (long long)sub, threads, sec, inter / sec / 1e9);
     return 0;
   }
   fprintf(stderr, "usage: see the comment at the top of nbody_host_cli.cc\n");

@@ -205,3 +205,30 @@ def test_simulate_mi355x_over_several_shards(tmp_path, name, shards):
     assert np.array_equal(out[:, :, 9], cpu[:, :, 9])
     scale = np.linalg.norm(cpu[1:, :, 6:9], axis=-1).max()
     assert np.abs(out[1:, :, 6:9] - cpu[1:, :, 6:9]).max() <= 1e-10 * scale
+
+
+def _cli_bench(*args):
+    import json
+    need_cli()
+    r = subprocess.run([str(CLI), "bench", *map(str, args)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    return json.loads(r.stdout.strip().splitlines()[-1]), r.stderr
+
+
+def test_cli_bench_on_host_paths():
+    """`nbody_host_cli bench`: the C++ bench driver (CLI args instead of the
+    reference's constexpr locals) over the library's scene generators."""
+    for ic, path in [("plummer", "avx2"), ("ring", "cpu"), ("cube", "avx2")]:
+        line, _ = _cli_bench(ic, 1024, path, 3, 2, 4)
+        assert line["bodies"] == 1024 and line["big_steps_timed"] == 2 and line["substeps"] == 2
+        assert line["Ginteractions_per_s"] > 0
+    need_cli()
+    r = subprocess.run([str(CLI), "bench", "plummer", "1024", "avx2", "1"], capture_output=True, text=True)
+    assert r.returncode == 2   # BIG >= 2: the first big step holds the set-up and is not timed
+
+
+@pytest.mark.gpu
+def test_cli_bench_mi355x():
+    line, status = _cli_bench("plummer", 65536, "mi355x", 3, 5)
+    assert "Simulation on MI355X succesfull." in status
+    assert line["Ginteractions_per_s"] > 500   # an AVX2 host does ~25; the kernels > 2000
