@@ -413,3 +413,63 @@ def test_equal_mass_forms_agree_with_general_form(precision, monkeypatch):
             assert rel_pos_err(a[0, :, :3], b[0, :, :3]) <= 1e-14
             fin_c, c = gpu_simulate(p, m, 1, 5, dt, precision=prec)  # and each form is reproducible
             assert np.array_equal(b, c) and np.array_equal(fin_b, fin_c)
+
+
+@pytest.mark.parametrize("n", [2047, 2048, 2049, 2305, 4095, 4097, 8191, 8193, 9217, 16383, 16385, 24577,
+                               32767, 32769, 49153, 65535, 65537, 67585, 131073])
+def test_automatic_plan_at_every_boundary(n):
+    """The library's own choice (variant 0) one body either side of everything that switches
+    it: the pair-symmetric threshold (2048), the slot rounding (256 / 1024 / 2048 at 8192 and
+    65 536), the block-size thresholds of make_plan (csrc/nbody_sym.hip) and ragged last
+    blocks.  Mixed masses (general form) and equal masses (deferred form), 3 small steps."""
+    rng = np.random.default_rng(n)
+    p, m = nb.ic_plummer(n, 900 + n)
+    for masses in (m, m * rng.uniform(0.5, 2.0, n)):
+        _, ref = ol.simulate(p, masses, 1, 3, 1e-3, threads=16)
+        _, out = gpu_simulate(p, masses, 1, 3, 1e-3)
+        assert rel_pos_err(out[0, :, :3], ref[0, :, :3]) <= 1e-14
+        assert vec_rel(out[0, :, 6:9], ref[0, :, 6:9]) <= 1e-12
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_scenes_against_oracle(seed):
+    """Seeded random scenes: size, mass spectrum (equal / log-uniform over 6 decades / a few
+    massless test bodies), softening, a bulk offset far from the origin (close pairs must not
+    cancel), coincident pairs; FP64 against the oracle, and the FP32 variant on the same
+    scene to its own bar."""
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.choice([3, 17, 300, 1000, 2048, 3000, 5000, 9000, 20000]))
+    eps2 = 0.0 if seed % 2 == 0 else 1e-4
+    if eps2 > 0.0:
+        n = min(n, 3000)   # softened scenes are checked by the direct O(n^2)-memory formula
+    p, m = nb.ic_plummer(n, 50 + seed)
+    kind = seed % 3
+    if kind == 1:
+        m = m * 10.0 ** rng.uniform(-3, 3, n)
+    elif kind == 2:
+        m = m.copy()
+        m[rng.choice(n, max(1, n // 10), replace=False)] = 0.0
+    if seed % 4 == 0:
+        p[:, :3] += np.array([1.0e3, -2.0e3, 5.0e2])     # cluster of size ~1 at distance ~2e3
+    if seed % 5 == 0 and n >= 4:
+        p[n // 2, :3] = p[n // 3, :3]                    # one coincident pair
+    if eps2 == 0.0:
+        fin, ref = ol.simulate(p, m, 1, 5, 1e-3, threads=16)
+    else:  # the oracle restates the reference, which has no softening: direct formula instead
+        d = p[None, :, :3] - p[:, None, :3]
+        r2 = (d ** 2).sum(-1) + eps2
+        acc = (m[None, :, None] * d / (r2 ** 1.5)[:, :, None]).sum(1) * nb.G_REFERENCE
+        _, out = gpu_simulate(p, m, 1, 1, 1e-3, eps2=eps2)
+        assert vec_rel(out[0, :, 6:9], acc) <= 1e-11
+        return
+    _, out = gpu_simulate(p, m, 1, 5, 1e-3)
+    off = np.linalg.norm(p[:, :3].mean(0))
+    assert rel_pos_err(out[0, :, :3], ref[0, :, :3]) <= 1e-14
+    mass_pos = m > 0
+    acc_ref = ref[0, :, 6:9]
+    scale = np.linalg.norm(acc_ref, axis=1).max()
+    assert np.abs(out[0, :, 6:9] - acc_ref).max() <= 1e-11 * scale
+    _, o32 = gpu_simulate(p, m, 1, 5, 1e-3, precision=nb.FP32)
+    if off < 1.0:
+        assert rel_pos_err(o32[0, :, :3], ref[0, :, :3]) <= FP32_TOL
+    assert mass_pos.any()
