@@ -69,6 +69,8 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--bodies", dest="n", type=int, default=1048576)
+    ap.add_argument("--ic", choices=["plummer", "cube"], default="plummer",
+                    help="plummer: BASELINE configs 3/4 (seed 42, dt 1e-3); cube: config 5 (uniform cube, seed 7, dt 1e-4)")
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--precision", choices=["fp64", "fp32"], default="fp64")
     ap.add_argument("--no-overlap", action="store_true")
@@ -116,8 +118,11 @@ def main():
 
     n, K, W = args.n, args.steps, args.warmup
     prec = nb.FP64 if args.precision == "fp64" else nb.FP32
-    p, m = nb.ic_plummer(n, 42)                       # same ICs on every rank
-    sim = ShardedNBody(p, m, 1e-3, rank=rank, world=world, device=device,
+    if args.ic == "plummer":                          # same ICs on every rank
+        (p, m), dt, scene = nb.ic_plummer(n, 42), 1e-3, f"plummer_sphere_n{n}_{args.precision}_seed42_dt1e-3"
+    else:
+        (p, m), dt, scene = nb.ic_uniform_cube(n, 7), 1e-4, f"uniform_cube_n{n}_{args.precision}_seed7_dt1e-4"
+    sim = ShardedNBody(p, m, dt, rank=rank, world=world, device=device,
                        backend=HipBackend(precision=prec, variant=args.variant),
                        overlap=not args.no_overlap, force_collectives=args.force_collectives)
     del p, m
@@ -164,7 +169,7 @@ def main():
             "value": round(value, 2), "unit": "Ginteractions/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": round(wall / K * 1e3, 3), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f64" if prec == nb.FP64 else "f32", "data": "synthetic",
-            "config": {"workload": f"plummer_sphere_n{n}_{args.precision}_seed42_dt1e-3",
+            "config": {"workload": scene,
                        "bodies": n, "interactions_per_step": inter_per_step,
                        "parallelism": (f"i-shard x{world}, RCCL all-gather of positions"
                                        + (" + reduce-scatter of pair-symmetric partial sums" if sim.acc_all is not None else "")

@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--precision", choices=["fp64", "fp32"], default="fp64")
+    ap.add_argument("--ic", choices=["plummer", "cube"], default="plummer")
     ap.add_argument("--no-overlap", action="store_true")
     args = ap.parse_args()
     import torch
@@ -35,8 +36,8 @@ def main():
     from nbody_mi355x.sharded import HipBackend, ShardedNBody
 
     prec = nb.FP64 if args.precision == "fp64" else nb.FP32
-    p, m = nb.ic_plummer(args.bodies, 42)
-    sim = ShardedNBody(p, m, 1e-3, rank=args.rank, world=args.world, device="cuda:0",
+    p, m = nb.ic_plummer(args.bodies, 42) if args.ic == "plummer" else nb.ic_uniform_cube(args.bodies, 7)
+    sim = ShardedNBody(p, m, 1e-3 if args.ic == "plummer" else 1e-4, rank=args.rank, world=args.world, device="cuda:0",
                        backend=HipBackend(precision=prec), overlap=not args.no_overlap,
                        force_collectives=True)
 
