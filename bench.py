@@ -35,7 +35,7 @@ FLOP_PER_INTERACTION = 20.0      # BASELINE.md section 3 / SURVEY 8d convention
 FP64_VECTOR_PEAK_TFLOPS = 78.6   # 256 CU x 64 FMA lanes x 2 x 2.4 GHz (MI355X_MICROARCH.md)
 
 
-def cpu_baseline(budget_s=15.0):
+def cpu_baseline(budget_s=20.0):
     """Time the reference's multithreaded AVX2 path on this host (bounded sample)."""
     import numpy as np  # noqa: F401
     import nbody_mi355x as nb
@@ -54,7 +54,7 @@ def cpu_baseline(budget_s=15.0):
         return time.perf_counter() - t0
 
     t_probe = run(2) / 2
-    sub = int(max(3, min(400, budget_s / max(t_probe, 1e-6))))
+    sub = int(max(3, min(600, budget_s / max(t_probe, 1e-6))))
     sec = run(sub)
     return {
         "value": round(n * n * sub / sec / 1e9, 3), "unit": "Ginteractions/s", "cores": threads,
