@@ -222,6 +222,59 @@ __global__ __launch_bounds__(kTile) void step_small_kernel(const nbody_mi355x_st
   if (r == 15 && li < a.own_count) integrate_and_store(a, li, xi, yi, zi, ax, ay, az);
 }
 
+// The same idea taken to the end for the smallest systems (the saturn ring's N = 500 is
+// BASELINE config 2): a whole WAVE per body.  Lane l takes the j bodies l, l+64, ... straight
+// from global memory (64 consecutive doubles per load, the arrays are L2-resident; no LDS
+// staging, no barrier), so a small step of 500 bodies is 8 pairs per lane on 125 workgroups
+// instead of 32 pairs per lane on 32, and nothing in the kernel waits on anything but its
+// own loads.  The 64 partial sums are added with the 4 row_shr steps above and 3 adds across
+// the rows' last lanes.  Lanes past the end of the j range take a valid slot with weight 0.
+__device__ __forceinline__ double wave_sum64(double v) {
+  v = row_sum16(v);  // lanes 15, 31, 47, 63 hold their rows' sums
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  double s = 0.0;
+#pragma unroll
+  for (int r = 0; r < 4; r++)
+    s += __hiloint2double(__builtin_amdgcn_readlane(hi, 16 * r + 15), __builtin_amdgcn_readlane(lo, 16 * r + 15));
+  return s;  // wave-uniform
+}
+
+template <int JPL>  // j bodies per lane held in registers at a time
+__global__ __launch_bounds__(kTile) void step_wave_kernel(const nbody_mi355x_step_args a) {
+  const int lane = threadIdx.x & 63;
+  const int64_t S = a.shard_slots;
+  const double eps2 = (a.eps2 > 0.0) ? a.eps2 : kTinyR2;
+  double c15 = 1.5, c1875 = 1.875;
+  asm volatile("" : "+v"(c15), "+v"(c1875));
+  const int64_t li = static_cast<int64_t>(blockIdx.x) * (kTile / 64) + (threadIdx.x >> 6);  // own body of this wave
+  const int64_t lc = li < S ? li : S - 1;
+  const double* own = a.pos_cur + static_cast<int64_t>(a.own_shard) * 3 * S;
+  const double xi = own[lc], yi = own[S + lc], zi = own[2 * S + lc];
+  double ax = 0.0, ay = 0.0, az = 0.0;
+  const int64_t jend = (a.j0_end + 63) & ~int64_t{63};
+  for (int64_t g = a.j0_begin; g < jend; g += 64 * JPL) {
+    double xj[JPL], yj[JPL], zj[JPL], mj[JPL];
+#pragma unroll
+    for (int u = 0; u < JPL; u++) {  // all loads of the trip are issued before the first use
+      int64_t j = g + 64 * u + lane;
+      const bool in = j < a.j0_end;
+      j = in ? j : a.j0_begin;  // (a valid slot; its weight is zeroed below)
+      const int64_t shard = j / S, off = j - shard * S;
+      const double* base = a.pos_cur + shard * 3 * S + off;
+      xj[u] = base[0];
+      yj[u] = base[S];
+      zj[u] = base[2 * S];
+      mj[u] = in ? a.mass[j] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < JPL; u++) pair_f64(xi, yi, zi, xj[u], yj[u], zj[u], mj[u], eps2, c15, c1875, ax, ay, az);
+  }
+  ax = wave_sum64(ax);
+  ay = wave_sum64(ay);
+  az = wave_sum64(az);
+  if (lane == 0 && li < a.own_count) integrate_and_store(a, li, xi, yi, zi, ax, ay, az);
+}
+
 // ------------------------------------------------------------ layout converters
 __global__ void pack_kernel(const double* __restrict__ aos, int64_t count, double* __restrict__ pos,
                             double* __restrict__ vel, int64_t S) {
@@ -334,6 +387,15 @@ hipError_t launch_step(const nbody_mi355x_step_args& a, hipStream_t stream) {
 bool small_applies(const nbody_mi355x_step_args& a) {
   return a.acc_in == nullptr && a.acc_out == nullptr && a.j1_begin == a.j1_end &&
          a.precision == NBODY_MI355X_FP64 && a.own_count <= 4096 && a.own_count > 0;
+}
+
+// a wave per body: whole steps over one j range, systems of at most kWaveMaxBodies bodies
+constexpr int64_t kWaveMaxBodies = 1024;
+hipError_t launch_wave(const nbody_mi355x_step_args& a, hipStream_t stream) {
+  if (!small_applies(a)) return hipErrorInvalidValue;
+  const unsigned blocks = static_cast<unsigned>((a.own_count + kTile / 64 - 1) / (kTile / 64));
+  hipLaunchKernelGGL(step_wave_kernel<8>, dim3(blocks), dim3(kTile), 0, stream, a);
+  return hipGetLastError();
 }
 
 hipError_t launch_small(const nbody_mi355x_step_args& a, hipStream_t stream) {
@@ -463,8 +525,12 @@ extern "C" int nbody_mi355x_step_f64(const nbody_mi355x_step_args* args, void* s
       case 4: e = launch_step<4, double, 2>(*args, s); break;
       case 5: e = launch_step<2, double, 8>(*args, s); break;
       case 6: e = launch_small(*args, s); break;
+      case 7: e = launch_wave(*args, s); break;
       default:
-        if (small_applies(*args)) { e = launch_small(*args, s); break; }
+        if (small_applies(*args)) {
+          e = (args->j0_end - args->j0_begin <= kWaveMaxBodies) ? launch_wave(*args, s) : launch_small(*args, s);
+          break;
+        }
         // enough workgroups to give every SIMD >= 2 waves with 2 bodies per lane?
         if (args->own_count >= 2 * 256 * 4 * 2 * 64) e = launch_step<2, double, 4>(*args, s);
         else e = launch_step<1, double, 8>(*args, s);

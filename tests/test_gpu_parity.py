@@ -73,7 +73,7 @@ def test_single_force_evaluation_accuracy():
     assert vec_rel(out[0, :, 6:9], g["out_cpu"][0, :, 6:9]) <= 1e-13
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7])
 def test_every_kernel_build_agrees(variant):
     g = load_golden("g4_plummer_1024")
     _, out = gpu_simulate(g["particles"], g["mass"], 1, 100, float(g["dt"]), variant=variant)
