@@ -125,6 +125,10 @@ typedef struct {
                              NBODY_MI355X_KICK_DRIFT                           */
 } nbody_mi355x_step_args;
 
+#define NBODY_MI355X_VARIANT_WAVE  7 /* one-sided, a wave per body (default up to 1024 bodies) */
+#define NBODY_MI355X_VARIANT_TINY  8 /* handle API only, at most 64 bodies: a whole big step in
+                                        one launch of one wave (the default there); variants
+                                        1-7 keep one launch per small step */
 #define NBODY_MI355X_VARIANT_SYM  10 /* pair-symmetric, block size chosen by the library */
 #define NBODY_MI355X_VARIANT_SYM1 11 /* pair-symmetric, 256-body blocks  */
 #define NBODY_MI355X_VARIANT_SYM2 12 /* pair-symmetric, 512-body blocks  */

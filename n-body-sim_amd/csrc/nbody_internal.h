@@ -10,6 +10,11 @@ void set_error(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
 // nbody_sym.hip: pair-symmetric step (args already validated by check_step_args)
 bool sym_supported(const nbody_mi355x_step_args& a, int64_t* preferred_bytes, int64_t* least_bytes);
 int sym_step(const nbody_mi355x_step_args& a, struct ihipStream_t* stream);
+// nbody_kernels.hip: `substeps` whole small steps of a system of at most kTinyMaxBodies bodies
+// in ONE launch of one wave (in place on a.pos_cur / a.vel; a.snapshot, if set, receives the
+// last small step's records).  One slab, FP64, no split ranges.
+constexpr int64_t kTinyMaxBodies = 64;
+int tiny_run(const nbody_mi355x_step_args& a, int64_t substeps, struct ihipStream_t* stream);
 // nbody_multi.hip: the handle over several shards / GPUs (host records already double)
 struct MultiSim;
 int multi_create(const nbody_mi355x_config& cfg, const int32_t* devices, int32_t num, MultiSim** out);

@@ -275,6 +275,61 @@ __global__ __launch_bounds__(kTile) void step_wave_kernel(const nbody_mi355x_ste
   if (lane == 0 && li < a.own_count) integrate_and_store(a, li, xi, yi, zi, ax, ay, az);
 }
 
+// ------------------------------------------------------------------ tiny systems
+// The reference's two-body and eight-body scenes (earth_moon.cc, slingshoot.cc,
+// earth_7moons.cc) take 324 000 small steps per big step; at one kernel per small step
+// (3.2 us, the floor of a dependent launch) a big step of the earth-moon scene would take a
+// second of pure launch latency.  Up to 64 bodies ONE WAVE carries the whole system: lane i
+// keeps body i's position and velocity in registers across `substeps` small steps, the
+// positions go round through LDS (two buffers alternating, one barrier per small step) and
+// are read back as broadcasts in the reference's order j = 0 .. N-1 (same summation order
+// as MakeSmallStep, particle_simulation.h:256-275).  In place: the state is read from and
+// written back to pos_cur / vel.
+__global__ __launch_bounds__(64) void step_tiny_kernel(const nbody_mi355x_step_args a, int64_t substeps) {
+  __shared__ JBody body[2][64];
+  const int i = threadIdx.x;
+  const int n = static_cast<int>(a.own_count);
+  const int64_t S = a.shard_slots;
+  const double eps2 = (a.eps2 > 0.0) ? a.eps2 : kTinyR2;
+  double c15 = 1.5, c1875 = 1.875;
+  asm volatile("" : "+v"(c15), "+v"(c1875));
+  const bool real = i < n;
+  const int ic = real ? i : 0;
+  double x = a.pos_cur[ic], y = a.pos_cur[S + ic], z = a.pos_cur[2 * S + ic];
+  double vx = a.vel[ic], vy = a.vel[S + ic], vz = a.vel[2 * S + ic];
+  const double m = real ? a.mass[ic] : 0.0;
+  const bool kd = a.integrator == NBODY_MI355X_KICK_DRIFT;
+  double ax = 0.0, ay = 0.0, az = 0.0;
+  for (int64_t k = 0; k < substeps; k++) {
+    JBody* buf = body[k & 1];
+    buf[i] = JBody{x, y, z, m};
+    __syncthreads();  // (buffer k&1 is next written two small steps on, past the next barrier)
+    ax = ay = az = 0.0;
+    for (int j = 0; j < n; j++) {
+      const JBody b = buf[j];
+      pair_f64(x, y, z, b.x, b.y, b.z, b.m, eps2, c15, c1875, ax, ay, az);
+    }
+    // ref: particle_simulation.h:288-300 (see integrate_and_store)
+    const double nvx = __builtin_fma(a.dt * ax, a.G, vx);
+    const double nvy = __builtin_fma(a.dt * ay, a.G, vy);
+    const double nvz = __builtin_fma(a.dt * az, a.G, vz);
+    x = __builtin_fma(a.dt, kd ? nvx : vx, x);
+    y = __builtin_fma(a.dt, kd ? nvy : vy, y);
+    z = __builtin_fma(a.dt, kd ? nvz : vz, z);
+    vx = nvx; vy = nvy; vz = nvz;
+  }
+  if (!real) return;
+  double* pos = const_cast<double*>(a.pos_cur);
+  pos[i] = x; pos[S + i] = y; pos[2 * S + i] = z;
+  a.vel[i] = vx; a.vel[S + i] = vy; a.vel[2 * S + i] = vz;
+  if (a.snapshot != nullptr) {
+    double* o = a.snapshot + 9 * i;
+    o[0] = x; o[1] = y; o[2] = z;
+    o[3] = vx; o[4] = vy; o[5] = vz;
+    o[6] = ax * a.G; o[7] = ay * a.G; o[8] = az * a.G;
+  }
+}
+
 // ------------------------------------------------------------ layout converters
 __global__ void pack_kernel(const double* __restrict__ aos, int64_t count, double* __restrict__ pos,
                             double* __restrict__ vel, int64_t S) {
@@ -419,6 +474,22 @@ void set_error(const char* fmt, ...) {
 }  // namespace nbody_internal
 
 using nbody_internal::set_error;
+
+int nbody_internal::tiny_run(const nbody_mi355x_step_args& a, int64_t substeps, hipStream_t stream) {
+  if (a.own_count < 1 || a.own_count > kTinyMaxBodies || a.num_shards != 1 || a.own_shard != 0 ||
+      a.precision != NBODY_MI355X_FP64 || !a.pos_cur || !a.vel || !a.mass || a.shard_slots < a.own_count ||
+      substeps < 1 || !(a.eps2 >= 0.0)) {
+    set_error("tiny_run: not a one-slab FP64 system of at most %lld bodies", (long long)kTinyMaxBodies);
+    return NBODY_MI355X_ERR_INVALID;
+  }
+  hipLaunchKernelGGL(step_tiny_kernel, dim3(1), dim3(64), 0, stream, a, substeps);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("tiny_run launch: %s", hipGetErrorString(e));
+    return NBODY_MI355X_ERR_LAUNCH;
+  }
+  return NBODY_MI355X_OK;
+}
 
 extern "C" const char* nbody_mi355x_last_error(void) { return nbody_internal::g_last_error; }
 

@@ -321,8 +321,19 @@ extern "C" int nbody_mi355x_run_async(nbody_mi355x_sim* s, int64_t substeps, voi
   a.workspace_bytes = s->workspace_bytes;
   HIP_TRY(hipEventRecord(s->ev0, s->stream), NBODY_MI355X_ERR_LAUNCH, "event record");
   int64_t k = 0;
+  // at most 64 bodies: the whole big step is ONE launch of one wave (tiny_run), in place on
+  // pos[cur] -- the reference's two- and eight-body scenes take 324 000 small steps per big step
+  if (s->n <= nbody_internal::kTinyMaxBodies && s->cfg.precision == NBODY_MI355X_FP64 &&
+      (s->cfg.variant == 0 || s->cfg.variant == NBODY_MI355X_VARIANT_TINY)) {
+    a.pos_cur = s->pos[s->cur];
+    a.pos_next = nullptr;
+    a.snapshot = snapshot_out ? s->aos : nullptr;
+    const int rc = nbody_internal::tiny_run(a, substeps, s->stream);
+    if (rc != NBODY_MI355X_OK) return rc;
+    k = substeps;
+  }
   const int64_t replayable = substeps - (snapshot_out ? 1 : 0);  // the snapshot step is launched plainly
-  if (s->n <= kGraphMaxBodies && replayable >= 2 * kGraphSteps && !s->graph_failed) {
+  if (k == 0 && s->n <= kGraphMaxBodies && replayable >= 2 * kGraphSteps && !s->graph_failed) {
     hipGraphExec_t& exec = s->graph[s->cur];
     if (!exec) {
       hipGraph_t graph = nullptr;

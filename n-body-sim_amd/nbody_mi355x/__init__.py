@@ -52,6 +52,7 @@ class StepArgs(C.Structure):
     ]
 
 
+VARIANT_WAVE, VARIANT_TINY = 7, 8
 VARIANT_SYM, VARIANT_SYM1, VARIANT_SYM2, VARIANT_SYM4, VARIANT_SYM8 = 10, 11, 12, 14, 18
 
 

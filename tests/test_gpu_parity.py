@@ -495,3 +495,30 @@ def test_energy_drift_at_scale_agrees_between_kernel_families():
     assert drift[2] != 0
     assert abs(drift[0] / drift[2] - 1) <= 0.01
     assert abs(drift[0]) <= 1e-3 * abs(ke0 + pe0)
+
+
+@pytest.mark.parametrize("n", [1, 2, 8, 33, 64])
+def test_tiny_systems_one_launch_per_big_step(n):
+    """Up to 64 bodies the handle API runs a whole big step in ONE launch of one wave
+    (step_tiny_kernel): same summation order as the reference, so the oracle to rounding; the
+    state carries over between big steps; and the per-small-step kernels (variant 7) agree."""
+    rng = np.random.default_rng(n)
+    p, m = nb.ic_plummer(max(n, 2), 70 + n)
+    p, m = p[:n].copy(), (m[:n] * rng.uniform(0.5, 2.0, n))
+    fin_ref, ref = ol.simulate(p, m, 3, 257, 1e-3, threads=2)
+    fin, out = gpu_simulate(p, m, 3, 257, 1e-3)
+    fin7, out7 = gpu_simulate(p, m, 3, 257, 1e-3, variant=7)
+    if n > 1:
+        assert rel_pos_err(out[:, :, :3], ref[:, :, :3]) <= 1e-13
+        assert vec_rel(out[:, :, 6:9], ref[:, :, 6:9]) <= 1e-12
+        assert rel_pos_err(out[:, :, :3], out7[:, :, :3]) <= 1e-13
+    else:  # one body: a = 0 exactly, straight-line motion
+        assert np.array_equal(out[:, :, 6:9], np.zeros((3, 1, 3)))
+        np.testing.assert_allclose(out[:, :, :3], ref[:, :, :3], rtol=1e-15, atol=0)
+    np.testing.assert_allclose(fin, fin_ref, rtol=1e-12, atol=1e-300)
+    # options the tiny kernel implements itself: softening and the kick-drift integrator
+    if n >= 2:
+        _, a = gpu_simulate(p, m, 1, 50, 1e-3, eps2=1e-3, integrator=nb.KICK_DRIFT)
+        _, b = gpu_simulate(p, m, 1, 50, 1e-3, eps2=1e-3, integrator=nb.KICK_DRIFT, variant=7)
+        assert rel_pos_err(a[0, :, :3], b[0, :, :3]) <= 1e-13
+        assert vec_rel(a[0, :, 3:6], b[0, :, 3:6]) <= 1e-12
