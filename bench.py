@@ -133,6 +133,7 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(device)
 
+    sim.warm_collectives()                            # first-call set-up of RCCL's collectives
     for _ in range(W):
         sim.step()
     barrier()

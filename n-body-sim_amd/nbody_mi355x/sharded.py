@@ -217,6 +217,19 @@ class ShardedNBody:
                 return True
         return _Done()
 
+    def warm_collectives(self):
+        """Run each collective of a small step once, on the real buffers, without changing the
+        state: the all-gather re-sends the own slab (already in place everywhere), the
+        reduce-scatter lands in the scratch the next step overwrites.  RCCL sets a collective
+        up on its first call (channels, kernels: milliseconds); a driver that times steps calls
+        this before its warm-up steps so that no timed step holds a first call."""
+        if not self.multi or self.device.type != "cuda":
+            return
+        self._all_gather(self.pos[self.cur], async_op=False)
+        if self.acc_all is not None:
+            self._reduce_scatter()
+        torch.cuda.synchronize(self.device)
+
     def sync_positions(self):
         """Make every slab of the current buffer current (needed before reading remote slabs)."""
         if self.multi and not self._fresh:

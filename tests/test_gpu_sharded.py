@@ -213,6 +213,7 @@ def _rccl_single_rank_main(port, n, steps, q):
         from nbody_mi355x.sharded import ShardedNBody
         p, m = nb.ic_plummer(n, 31)
         sim = ShardedNBody(p, m, 1e-3, rank=0, world=1, device="cuda:0", overlap=True, force_collectives=True)
+        sim.warm_collectives()   # as bench.py does: must not change the state
         for k in range(steps):
             sim.step(snapshot=(k == steps - 1))
         torch.cuda.synchronize()
