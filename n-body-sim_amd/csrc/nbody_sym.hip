@@ -395,7 +395,9 @@ __device__ __forceinline__ void sum_partials(const SymArgs& sa, int slab, int64_
   const int J = slab * sa.nbs + static_cast<int>(off / B);
   const int jl = static_cast<int>(off % B);
   double x = 0.0, y = 0.0, z = 0.0;
+  // (unrolled so that several partials' loads are in flight; the order of the adds is unchanged)
   if (own_slab) {
+#pragma unroll 8
     for (int s = sa.r_first; s < sa.nR; s++) {
       const double* Rs = sa.R + static_cast<int64_t>(s) * 3 * S + off;
       x += Rs[0];
@@ -404,6 +406,7 @@ __device__ __forceinline__ void sum_partials(const SymArgs& sa, int slab, int64_
     }
   }
   const int d_min = sa.d_lo > 1 ? sa.d_lo : 1;
+#pragma unroll 4
   for (int il = 0; il < sa.nbs; il++) {
     const int I = sa.row0 + il;
     int d = J - I;
