@@ -232,3 +232,37 @@ def test_cli_bench_mi355x():
     line, status = _cli_bench("plummer", 65536, "mi355x", 3, 5)
     assert "Simulation on MI355X succesfull." in status
     assert line["Ginteractions_per_s"] > 500   # an AVX2 host does ~25; the kernels > 2000
+
+
+@pytest.mark.gpu
+def test_reference_saturn_ring_main_on_the_gpu(tmp_path):
+    """The reference's OWN saturn_ring.cc with the one `Simulate` line swapped for
+    SimulateMI355X() (built in the build container by `make -C oracle ref-scenes` against this
+    repository's headers; the source is never copied): the whole scene as its author set it up
+    -- N = 500, 400 big steps x 21 600 small steps -- on the GPU.  Its text output must equal,
+    byte for byte, what this repository's own driver writes for the same scene's first big steps (whose set-up is
+    pinned bit for bit to the reference's, test_scene_setup_matches_reference_bit_for_bit, and
+    whose GPU path is pinned to the golden vectors, test_simulate_mi355x_drop_in)."""
+    exe = REPO / "oracle" / "_ref" / "saturn_ring_mi355x"
+    if not exe.exists():
+        pytest.skip("oracle/_ref/saturn_ring_mi355x not built (needs the reference mounted at build time)")
+    need_cli()
+    a, b = tmp_path / "ref_main", tmp_path / "cli"
+    a.mkdir(); b.mkdir()
+    r = subprocess.run([str(exe)], cwd=a, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    assert "Simulation on MI355X succesfull." in r.stdout
+    # the driver's run is cut after 8 of the 400 big steps (same step size and substeps: they
+    # derive from the scene's own 400, not from the count run): files 0 .. 8 must match
+    r = subprocess.run([str(CLI), "demo", "saturn_ring", "mi355x", "8", "1", str(b) + "/"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    fa = sorted(f.name for f in a.glob("N_Body_Timestep_*.txt"))
+    fb = sorted(f.name for f in b.glob("N_Body_Timestep_*.txt"))
+    assert len(fa) == 401 and len(fb) == 9 and fa[:9] == fb
+    for name in fb:
+        assert (a / name).read_bytes() == (b / name).read_bytes(), name
+    last = np.loadtxt(a / fa[-1])
+    assert last.shape == (500, 11) and np.isfinite(last).all()
+    radius = np.linalg.norm(last[1:, 1:4], axis=1)
+    assert 2e7 < radius.min() and radius.max() < 5e8    # still a ring after one day
