@@ -165,6 +165,11 @@ def main():
                 traffic = json.loads(tf.read_text()).get(f"n{n}_{args.precision}")
             except Exception:
                 traffic = None
+        uses_sym = sim.workspace is not None and args.variant in (0, 10, 11, 12, 14, 18) and not (
+            args.variant == 0 and world == 1 and prec == nb.FP64 and n <= nb.WAVE_MAX_BODIES)
+        kernel_label = ("pair-symmetric tiles + finish" if uses_sym else
+                        "one-sided step_wave_kernel" if (world == 1 and prec == nb.FP64 and n <= nb.WAVE_MAX_BODIES
+                                                         and args.variant in (0, 7)) else "one-sided step_kernel")
         line = {
             "metric": "Ginteractions/s at N=1M fp64, 1/2/4/8 MI355X; % of FP64 vector peak",
             "value": round(value, 2), "unit": "Ginteractions/s", "n_gpus": world, "steps": K, "warmup": W,
@@ -176,13 +181,12 @@ def main():
                                        + (" + reduce-scatter of pair-symmetric partial sums" if sim.acc_all is not None else "")
                                        + " per step"
                                        + ("" if args.no_overlap or world == 1 else ", all-gather overlapped with the own-slab part")),
-                       "kernel": ("pair-symmetric tiles + finish" if sim.workspace is not None and args.variant in (0, 10, 11, 12, 14, 18)
-                                  else "one-sided step_kernel"),
+                       "kernel": kernel_label,
                        "kernel_variant": args.variant},
             "roofline": {"bound": "valu_fp64" if prec == nb.FP64 else "valu_fp32", "achieved": round(ach, 3),
                          "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
-                         "kernel": ("sym_tiles_kernel+sym_finish_kernel" if sim.workspace is not None and args.variant in (0, 10, 11, 12, 14, 18)
-                                    else "step_kernel"), "avg_launch_ms": round(dev_s / K * 1e3, 3),
+                         "kernel": ("sym_tiles_kernel+sym_finish_kernel" if uses_sym else kernel_label.split()[-1]),
+                         "avg_launch_ms": round(dev_s / K * 1e3, 3),
                          "flop_per_interaction": FLOP_PER_INTERACTION},
             "pct_of_fp64_vector_peak": round(100 * ach / FP64_VECTOR_PEAK_TFLOPS, 2),
         }

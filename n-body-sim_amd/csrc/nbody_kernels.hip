@@ -22,6 +22,7 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "nbody_device.hpp"
@@ -239,40 +240,76 @@ __device__ __forceinline__ double wave_sum64(double v) {
   return s;  // wave-uniform
 }
 
-template <int JPL>  // j bodies per lane held in registers at a time
+// JPL: j bodies per lane held in registers per trip; IPW: own bodies per wave (each j body
+// fetched serves IPW pairs).  The NEXT trip's j bodies are requested before this trip's pairs
+// are evaluated (two register sets used alternately), so that the L2 latency of a trip's 4 JPL
+// loads lies under the previous trip's arithmetic instead of in front of its own.
+template <int JPL>
+struct JSet {
+  double x[JPL], y[JPL], z[JPL], m[JPL];
+};
+template <int JPL>
+__device__ __forceinline__ void wave_fetch(const nbody_mi355x_step_args& a, int64_t g, int lane, JSet<JPL>& b) {
+  const int64_t S = a.shard_slots;
+#pragma unroll
+  for (int u = 0; u < JPL; u++) {
+    // the slab of a 64-slot group is wave-uniform (S is a multiple of 64): scalar arithmetic,
+    // and none at all on one slab
+    int64_t gu = g + 64 * u;
+    if (gu >= a.j0_end) gu = a.j0_begin;  // (a whole group past the end: any valid group, weights zeroed)
+    const int64_t shard = a.num_shards == 1 ? 0 : gu / S;
+    const double* base = a.pos_cur + shard * 2 * S + gu + lane;  // = slab * 3S + (gu - slab * S) + lane
+    const bool in = g + 64 * u + lane < a.j0_end;
+    b.x[u] = base[0];
+    b.y[u] = base[S];
+    b.z[u] = base[2 * S];
+    b.m[u] = in ? a.mass[gu + lane] : 0.0;
+  }
+}
+
+template <int JPL, int IPW>
 __global__ __launch_bounds__(kTile) void step_wave_kernel(const nbody_mi355x_step_args a) {
   const int lane = threadIdx.x & 63;
   const int64_t S = a.shard_slots;
   const double eps2 = (a.eps2 > 0.0) ? a.eps2 : kTinyR2;
   double c15 = 1.5, c1875 = 1.875;
   asm volatile("" : "+v"(c15), "+v"(c1875));
-  const int64_t li = static_cast<int64_t>(blockIdx.x) * (kTile / 64) + (threadIdx.x >> 6);  // own body of this wave
-  const int64_t lc = li < S ? li : S - 1;
+  // own bodies of this wave: IPW consecutive slots
+  const int64_t li0 = (static_cast<int64_t>(blockIdx.x) * (kTile / 64) + (threadIdx.x >> 6)) * IPW;
   const double* own = a.pos_cur + static_cast<int64_t>(a.own_shard) * 3 * S;
-  const double xi = own[lc], yi = own[S + lc], zi = own[2 * S + lc];
-  double ax = 0.0, ay = 0.0, az = 0.0;
-  const int64_t jend = (a.j0_end + 63) & ~int64_t{63};
-  for (int64_t g = a.j0_begin; g < jend; g += 64 * JPL) {
-    double xj[JPL], yj[JPL], zj[JPL], mj[JPL];
+  double xi[IPW], yi[IPW], zi[IPW], ax[IPW], ay[IPW], az[IPW];
 #pragma unroll
-    for (int u = 0; u < JPL; u++) {  // all loads of the trip are issued before the first use
-      int64_t j = g + 64 * u + lane;
-      const bool in = j < a.j0_end;
-      j = in ? j : a.j0_begin;  // (a valid slot; its weight is zeroed below)
-      const int64_t shard = j / S, off = j - shard * S;
-      const double* base = a.pos_cur + shard * 3 * S + off;
-      xj[u] = base[0];
-      yj[u] = base[S];
-      zj[u] = base[2 * S];
-      mj[u] = in ? a.mass[j] : 0.0;
-    }
-#pragma unroll
-    for (int u = 0; u < JPL; u++) pair_f64(xi, yi, zi, xj[u], yj[u], zj[u], mj[u], eps2, c15, c1875, ax, ay, az);
+  for (int k = 0; k < IPW; k++) {
+    const int64_t lc = li0 + k < S ? li0 + k : S - 1;
+    xi[k] = own[lc]; yi[k] = own[S + lc]; zi[k] = own[2 * S + lc];
+    ax[k] = ay[k] = az[k] = 0.0;
   }
-  ax = wave_sum64(ax);
-  ay = wave_sum64(ay);
-  az = wave_sum64(az);
-  if (lane == 0 && li < a.own_count) integrate_and_store(a, li, xi, yi, zi, ax, ay, az);
+  const int64_t jend = (a.j0_end + 63) & ~int64_t{63};
+  constexpr int64_t kTrip = 64 * JPL;
+  auto pairs = [&](const JSet<JPL>& b) {
+#pragma unroll
+    for (int u = 0; u < JPL; u++)
+#pragma unroll
+      for (int k = 0; k < IPW; k++)
+        pair_f64(xi[k], yi[k], zi[k], b.x[u], b.y[u], b.z[u], b.m[u], eps2, c15, c1875, ax[k], ay[k], az[k]);
+  };
+  JSet<JPL> b0, b1;
+  int64_t g = a.j0_begin;
+  if (g < jend) wave_fetch<JPL>(a, g, lane, b0);
+  while (g < jend) {
+    if (g + kTrip < jend) wave_fetch<JPL>(a, g + kTrip, lane, b1);
+    pairs(b0);
+    g += kTrip;
+    if (g >= jend) break;
+    if (g + kTrip < jend) wave_fetch<JPL>(a, g + kTrip, lane, b0);
+    pairs(b1);
+    g += kTrip;
+  }
+#pragma unroll
+  for (int k = 0; k < IPW; k++) {
+    const double sx = wave_sum64(ax[k]), sy = wave_sum64(ay[k]), sz = wave_sum64(az[k]);
+    if (lane == 0 && li0 + k < a.own_count) integrate_and_store(a, li0 + k, xi[k], yi[k], zi[k], sx, sy, sz);
+  }
 }
 
 // ------------------------------------------------------------------ tiny systems
@@ -439,18 +476,29 @@ hipError_t launch_step(const nbody_mi355x_step_args& a, hipStream_t stream) {
 }
 
 // The small-system kernel handles whole, unsplit steps over one j range.
-bool small_applies(const nbody_mi355x_step_args& a) {
+bool small_applies(const nbody_mi355x_step_args& a, int64_t max_bodies = 4096) {
   return a.acc_in == nullptr && a.acc_out == nullptr && a.j1_begin == a.j1_end &&
-         a.precision == NBODY_MI355X_FP64 && a.own_count <= 4096 && a.own_count > 0;
+         a.precision == NBODY_MI355X_FP64 && a.own_count <= max_bodies && a.own_count > 0;
 }
 
-// a wave per body: whole steps over one j range, systems of at most kWaveMaxBodies bodies
-constexpr int64_t kWaveMaxBodies = 1024;
-hipError_t launch_wave(const nbody_mi355x_step_args& a, hipStream_t stream) {
-  if (!small_applies(a)) return hipErrorInvalidValue;
-  const unsigned blocks = static_cast<unsigned>((a.own_count + kTile / 64 - 1) / (kTile / 64));
-  hipLaunchKernelGGL(step_wave_kernel<8>, dim3(blocks), dim3(kTile), 0, stream, a);
+// a wave per IPW bodies: whole steps over one j range of at most NBODY_MI355X_WAVE_MAX_BODIES
+// slots.  Shapes and thresholds from tools/sweep_small.py on MI355X (microseconds per small
+// step, graph-replayed; pair-symmetric kernels in brackets): 500 bodies 3.9, 1024 5.1 (42),
+// 2048 9.2 (43), 4096 20.1 (45), 6000 46.8 (56.5), 8192 60.3 (60.8) -- above ~7000 bodies the
+// pair-symmetric kernels' halved arithmetic outweighs their fixed cost of ~40 us per step.
+constexpr int64_t kWaveMaxBodies = NBODY_MI355X_WAVE_MAX_BODIES;
+template <int JPL, int IPW>
+hipError_t launch_wave_t(const nbody_mi355x_step_args& a, hipStream_t stream) {
+  const int64_t waves = (a.own_count + IPW - 1) / IPW;
+  const unsigned blocks = static_cast<unsigned>((waves + kTile / 64 - 1) / (kTile / 64));
+  hipLaunchKernelGGL((step_wave_kernel<JPL, IPW>), dim3(blocks), dim3(kTile), 0, stream, a);
   return hipGetLastError();
+}
+hipError_t launch_wave(const nbody_mi355x_step_args& a, hipStream_t stream) {
+  if (!small_applies(a, 65536)) return hipErrorInvalidValue;
+  if (a.own_count <= 1024) return launch_wave_t<8, 1>(a, stream);
+  if (a.own_count <= 2560) return launch_wave_t<8, 2>(a, stream);
+  return launch_wave_t<8, 4>(a, stream);
 }
 
 hipError_t launch_small(const nbody_mi355x_step_args& a, hipStream_t stream) {
@@ -507,9 +555,8 @@ extern "C" int nbody_mi355x_device_count(int* count) {
   return NBODY_MI355X_OK;
 }
 
-// Below this many bodies the one-sided kernel is used by default (measured cross-over on
-// MI355X is below 4096 bodies: 226 vs 77 Ginteractions/s there; both are launch-bound
-// further down, and the one-sided kernel keeps the reference's summation order).
+// The pair-symmetric kernels apply from this many bodies; by default they take over above
+// NBODY_MI355X_WAVE_MAX_BODIES (launch_wave), or where a step is split or spans two j ranges.
 static constexpr int64_t kSymMinBodies = 2048;
 
 // Host-side shape checks: everything the kernel's indexing assumes is verified
@@ -570,7 +617,8 @@ extern "C" int nbody_mi355x_step_f64(const nbody_mi355x_step_args* args, void* s
   hipStream_t s = static_cast<hipStream_t>(stream);
   hipError_t e;
   if (is_sym_variant(args->variant)) return nbody_internal::sym_step(*args, s);
-  if (args->variant == 0 && args->workspace != nullptr &&
+  const bool wave_size = small_applies(*args, kWaveMaxBodies) && args->j0_end - args->j0_begin <= kWaveMaxBodies;
+  if (args->variant == 0 && !wave_size && args->workspace != nullptr &&
       args->acc_in == nullptr && args->acc_out == nullptr && args->own_count >= kSymMinBodies &&
       args->j0_begin == 0 && args->j1_begin == args->j1_end &&
       args->j0_end >= args->own_count) {
@@ -598,10 +646,7 @@ extern "C" int nbody_mi355x_step_f64(const nbody_mi355x_step_args* args, void* s
       case 6: e = launch_small(*args, s); break;
       case 7: e = launch_wave(*args, s); break;
       default:
-        if (small_applies(*args)) {
-          e = (args->j0_end - args->j0_begin <= kWaveMaxBodies) ? launch_wave(*args, s) : launch_small(*args, s);
-          break;
-        }
+        if (wave_size) { e = launch_wave(*args, s); break; }
         // enough workgroups to give every SIMD >= 2 waves with 2 bodies per lane?
         if (args->own_count >= 2 * 256 * 4 * 2 * 64) e = launch_step<2, double, 4>(*args, s);
         else e = launch_step<1, double, 8>(*args, s);

@@ -53,6 +53,7 @@ class StepArgs(C.Structure):
 
 
 VARIANT_WAVE, VARIANT_TINY = 7, 8
+WAVE_MAX_BODIES = 7168   # NBODY_MI355X_WAVE_MAX_BODIES: below, whole FP64 steps take the wave kernels
 VARIANT_SYM, VARIANT_SYM1, VARIANT_SYM2, VARIANT_SYM4, VARIANT_SYM8 = 10, 11, 12, 14, 18
 
 

@@ -110,3 +110,13 @@ def test_shard_partition_matches_reference_threads(n, world):
     assert begins == [sum(counts[:r]) for r in range(world)]
     if (n, world) == (5, 3):
         assert counts == [2, 2, 1]
+
+
+def test_python_constants_mirror_the_header():
+    import re
+    text = (REPO / "include" / "nbody_mi355x.h").read_text()
+    defs = {k: v for k, v in re.findall(r"#define\s+NBODY_MI355X_(\w+)\s+([-\w.+]+)", text)}
+    assert int(defs["WAVE_MAX_BODIES"]) == nb.WAVE_MAX_BODIES
+    assert int(defs["VARIANT_WAVE"]) == nb.VARIANT_WAVE and int(defs["VARIANT_TINY"]) == nb.VARIANT_TINY
+    assert int(defs["VARIANT_SYM"]) == nb.VARIANT_SYM and int(defs["VARIANT_SYM8"]) == nb.VARIANT_SYM8
+    assert int(defs["TILE"]) == nb.TILE and float(defs["G_REFERENCE"]) == nb.G_REFERENCE

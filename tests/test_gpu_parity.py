@@ -415,13 +415,15 @@ def test_equal_mass_forms_agree_with_general_form(precision, monkeypatch):
             assert np.array_equal(b, c) and np.array_equal(fin_b, fin_c)
 
 
-@pytest.mark.parametrize("n", [2047, 2048, 2049, 2305, 4095, 4097, 8191, 8193, 9217, 16383, 16385, 24577,
+@pytest.mark.parametrize("n", [63, 64, 65, 1023, 1024, 1025, 2047, 2048, 2049, 2305, 2559, 2560, 2561, 4095,
+                               4097, 7167, 7168, 7169, 8191, 8193, 9217, 16383, 16385, 24577,
                                32767, 32769, 49153, 65535, 65537, 67585, 131073])
 def test_automatic_plan_at_every_boundary(n):
     """The library's own choice (variant 0) one body either side of everything that switches
-    it: the pair-symmetric threshold (2048), the slot rounding (256 / 1024 / 2048 at 8192 and
-    65 536), the block-size thresholds of make_plan (csrc/nbody_sym.hip) and ragged last
-    blocks.  Mixed masses (general form) and equal masses (deferred form), 3 small steps."""
+    it: one wave for the whole system (64), the wave kernels' shapes (1024, 2560) and their end
+    (NBODY_MI355X_WAVE_MAX_BODIES = 7168, the pair-symmetric kernels beyond), the slot rounding
+    (256 / 1024 / 2048 at 8192 and 65 536), the block-size thresholds of make_plan
+    (csrc/nbody_sym.hip) and ragged last blocks.  Mixed masses (general form) and equal masses (deferred form), 3 small steps."""
     rng = np.random.default_rng(n)
     p, m = nb.ic_plummer(n, 900 + n)
     for masses in (m, m * rng.uniform(0.5, 2.0, n)):
