@@ -388,8 +388,13 @@ __global__ __launch_bounds__(256) void sym_tiles_kernel(const SymArgs a) {
 // g = (slab, off), added in a fixed order: the own rows' i-side chunks R[r_first..nR) (own
 // slab only) and, for every own row I that met g's block J at a distance d = J - I (mod nb)
 // inside [max(d_lo,1), d_hi], the j-side sums C[d - c_base][I][.].
+// The list of partials is dealt over kParts threads per slot (part p takes every kParts-th
+// chunk and row), whose sums are then added in part order through LDS: 4x the loads in
+// flight on these memory-bound kernels (a slot has up to ~300 partials of 24 bytes), still one
+// fixed order of additions.
+constexpr int kParts = 4;
 template <int B>
-__device__ __forceinline__ void sum_partials(const SymArgs& sa, int slab, int64_t off, bool own_slab,
+__device__ __forceinline__ void sum_partials(const SymArgs& sa, int slab, int64_t off, bool own_slab, int part,
                                              double* ax, double* ay, double* az) {
   const int64_t S = sa.S;
   const int J = slab * sa.nbs + static_cast<int>(off / B);
@@ -397,8 +402,8 @@ __device__ __forceinline__ void sum_partials(const SymArgs& sa, int slab, int64_
   double x = 0.0, y = 0.0, z = 0.0;
   // (unrolled so that several partials' loads are in flight; the order of the adds is unchanged)
   if (own_slab) {
-#pragma unroll 8
-    for (int s = sa.r_first; s < sa.nR; s++) {
+#pragma unroll 4
+    for (int s = sa.r_first + part; s < sa.nR; s += kParts) {
       const double* Rs = sa.R + static_cast<int64_t>(s) * 3 * S + off;
       x += Rs[0];
       y += Rs[S];
@@ -407,7 +412,7 @@ __device__ __forceinline__ void sum_partials(const SymArgs& sa, int slab, int64_
   }
   const int d_min = sa.d_lo > 1 ? sa.d_lo : 1;
 #pragma unroll 4
-  for (int il = 0; il < sa.nbs; il++) {
+  for (int il = part; il < sa.nbs; il += kParts) {
     const int I = sa.row0 + il;
     int d = J - I;
     if (d < 0) d += sa.nb;
@@ -420,15 +425,38 @@ __device__ __forceinline__ void sum_partials(const SymArgs& sa, int slab, int64_
   *ax = x; *ay = y; *az = z;
 }
 
+// The kParts partial sums of the workgroup's 64 slots, added in part order; valid for part 0.
+// blockDim = (64, kParts): threadIdx.x = slot within the workgroup, threadIdx.y = part.
+__device__ __forceinline__ void combine_parts(double* ax, double* ay, double* az) {
+  __shared__ double red[3][kParts][64];
+  const int l = threadIdx.x, p = threadIdx.y;
+  red[0][p][l] = *ax;
+  red[1][p][l] = *ay;
+  red[2][p][l] = *az;
+  __syncthreads();
+  if (p == 0) {
+    double x = red[0][0][l], y = red[1][0][l], z = red[2][0][l];
+#pragma unroll
+    for (int q = 1; q < kParts; q++) {
+      x += red[0][q][l];
+      y += red[1][q][l];
+      z += red[2][q][l];
+    }
+    *ax = x; *ay = y; *az = z;
+  }
+}
+
 // one slab, one batch: the partial sums are the complete sums -> integrate directly
 template <int IPT>
 __global__ __launch_bounds__(256) void sym_finish_kernel(const SymArgs sa, const nbody_mi355x_step_args a) {
-  const int64_t g = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
-  if (g >= a.own_count) return;
+  const int64_t g = static_cast<int64_t>(blockIdx.x) * 64 + threadIdx.x;
+  const bool real = g < a.own_count;
   const int64_t S = sa.S;
-  double ax, ay, az;
-  sum_partials<256 * IPT>(sa, 0, g, true, &ax, &ay, &az);
-  integrate_and_store(a, g, a.pos_cur[g], a.pos_cur[S + g], a.pos_cur[2 * S + g], ax, ay, az);
+  double ax = 0.0, ay = 0.0, az = 0.0;
+  if (real) sum_partials<256 * IPT>(sa, 0, g, true, threadIdx.y, &ax, &ay, &az);
+  combine_parts(&ax, &ay, &az);
+  if (real && threadIdx.y == 0)
+    integrate_and_store(a, g, a.pos_cur[g], a.pos_cur[S + g], a.pos_cur[2 * S + g], ax, ay, az);
 }
 
 // several slabs (ranks) and/or several batches: this rank's partial sums of this batch for
@@ -437,12 +465,14 @@ template <int IPT>
 __global__ __launch_bounds__(256) void sym_gather_kernel(const SymArgs sa, int own_shard, int num_shards,
                                                          bool first, double* __restrict__ out) {
   const int64_t S = sa.S;
-  const int64_t g = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
-  if (g >= S * num_shards) return;
-  const int slab = static_cast<int>(g / S);
-  const int64_t off = g - static_cast<int64_t>(slab) * S;
-  double ax, ay, az;
-  sum_partials<256 * IPT>(sa, slab, off, slab == own_shard, &ax, &ay, &az);
+  const int64_t g = static_cast<int64_t>(blockIdx.x) * 64 + threadIdx.x;
+  const bool real = g < S * num_shards;
+  const int slab = real ? static_cast<int>(g / S) : 0;
+  const int64_t off = real ? g - static_cast<int64_t>(slab) * S : 0;
+  double ax = 0.0, ay = 0.0, az = 0.0;
+  if (real) sum_partials<256 * IPT>(sa, slab, off, slab == own_shard, threadIdx.y, &ax, &ay, &az);
+  combine_parts(&ax, &ay, &az);
+  if (!real || threadIdx.y != 0) return;
   double* o = out + static_cast<int64_t>(slab) * 3 * S + off;
   if (first) {
     o[0] = ax;
@@ -590,12 +620,12 @@ hipError_t launch(SymArgs sa, const nbody_mi355x_step_args& a, hipStream_t strea
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (only && a.acc_out == nullptr) {
-      hipLaunchKernelGGL((sym_finish_kernel<IPT>), dim3(static_cast<unsigned>((a.own_count + 255) / 256)),
-                         dim3(256), 0, stream, sa, a);
+      hipLaunchKernelGGL((sym_finish_kernel<IPT>), dim3(static_cast<unsigned>((a.own_count + 63) / 64)),
+                         dim3(64, kParts), 0, stream, sa, a);
       return hipGetLastError();
     }
     const int64_t total = sa.S * a.num_shards;
-    hipLaunchKernelGGL((sym_gather_kernel<IPT>), dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0,
+    hipLaunchKernelGGL((sym_gather_kernel<IPT>), dim3(static_cast<unsigned>((total + 63) / 64)), dim3(64, kParts), 0,
                        stream, sa, a.own_shard, a.num_shards, first, out);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
