@@ -47,9 +47,11 @@ typedef enum {
 
 /* Arithmetic of the force accumulation. */
 #define NBODY_MI355X_FP64 0 /* everything in double (parity path)                */
-#define NBODY_MI355X_FP32 1 /* forces in float: r^2, r^-3 and the running sums (and,
-                               in the pair-symmetric kernels, the separations);
-                               state, integration and snapshots stay double       */
+#define NBODY_MI355X_FP32 1 /* forces MAY be evaluated in float: r^2, r^-3 and the running
+                               sums (and, in the pair-symmetric kernels, the separations);
+                               state, integration and snapshots stay double.  Systems of
+                               at most NBODY_MI355X_WAVE_MAX_BODIES bodies are latency-bound
+                               and run the double kernels either way (faster there)     */
 
 /* Time integrator fused into the step's epilogue.
  * EULER: the reference's forward Euler, v' = v + dt a, r' = r + dt v (OLD v)

@@ -476,9 +476,12 @@ hipError_t launch_step(const nbody_mi355x_step_args& a, hipStream_t stream) {
 }
 
 // The small-system kernel handles whole, unsplit steps over one j range.
+// (Precision: these kernels compute in double.  A caller that ALLOWS float forces,
+// NBODY_MI355X_FP32, is served by them too where they are the fastest path: at these sizes a
+// step is bound by latency and launch, not by arithmetic, and the float kernels are slower.)
 bool small_applies(const nbody_mi355x_step_args& a, int64_t max_bodies = 4096) {
-  return a.acc_in == nullptr && a.acc_out == nullptr && a.j1_begin == a.j1_end &&
-         a.precision == NBODY_MI355X_FP64 && a.own_count <= max_bodies && a.own_count > 0;
+  return a.acc_in == nullptr && a.acc_out == nullptr && a.j1_begin == a.j1_end && a.own_count <= max_bodies &&
+         a.own_count > 0;
 }
 
 // a wave per IPW bodies: whole steps over one j range of at most NBODY_MI355X_WAVE_MAX_BODIES
@@ -525,9 +528,9 @@ using nbody_internal::set_error;
 
 int nbody_internal::tiny_run(const nbody_mi355x_step_args& a, int64_t substeps, hipStream_t stream) {
   if (a.own_count < 1 || a.own_count > kTinyMaxBodies || a.num_shards != 1 || a.own_shard != 0 ||
-      a.precision != NBODY_MI355X_FP64 || !a.pos_cur || !a.vel || !a.mass || a.shard_slots < a.own_count ||
+      !a.pos_cur || !a.vel || !a.mass || a.shard_slots < a.own_count ||
       substeps < 1 || !(a.eps2 >= 0.0)) {
-    set_error("tiny_run: not a one-slab FP64 system of at most %lld bodies", (long long)kTinyMaxBodies);
+    set_error("tiny_run: not a one-slab system of at most %lld bodies", (long long)kTinyMaxBodies);
     return NBODY_MI355X_ERR_INVALID;
   }
   hipLaunchKernelGGL(step_tiny_kernel, dim3(1), dim3(64), 0, stream, a, substeps);
@@ -630,7 +633,9 @@ extern "C" int nbody_mi355x_step_f64(const nbody_mi355x_step_args* args, void* s
     if (nbody_internal::sym_supported(a, &preferred, &least) && least <= a.workspace_bytes)
       return nbody_internal::sym_step(a, s);
   }
-  if (args->precision == NBODY_MI355X_FP32) {
+  if (args->variant == 0 && wave_size) {
+    e = launch_wave(*args, s);
+  } else if (args->precision == NBODY_MI355X_FP32) {
     switch (args->variant) {
       case 1: e = launch_step<1, float, 8>(*args, s); break;
       case 4: e = launch_step<4, float, 4>(*args, s); break;

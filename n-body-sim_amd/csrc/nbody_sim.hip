@@ -323,7 +323,7 @@ extern "C" int nbody_mi355x_run_async(nbody_mi355x_sim* s, int64_t substeps, voi
   int64_t k = 0;
   // at most 64 bodies: the whole big step is ONE launch of one wave (tiny_run), in place on
   // pos[cur] -- the reference's two- and eight-body scenes take 324 000 small steps per big step
-  if (s->n <= nbody_internal::kTinyMaxBodies && s->cfg.precision == NBODY_MI355X_FP64 &&
+  if (s->n <= nbody_internal::kTinyMaxBodies &&
       (s->cfg.variant == 0 || s->cfg.variant == NBODY_MI355X_VARIANT_TINY)) {
     a.pos_cur = s->pos[s->cur];
     a.pos_next = nullptr;
