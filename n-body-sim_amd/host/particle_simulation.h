@@ -343,6 +343,15 @@ class ParticleSimulation {
     return true;
   }
 
+  // The reference's accelerator entry point by its own name (ref: particle_simulation.h:559,
+  // defined in particle_simulation_GPU.cu:277-303, which a GPU scene #includes instead of this
+  // header, saturn_ring.cu:6-8): same call shape, runs the MI355X path.  `blocksize` was the
+  // CUDA launch's block size (.cu:147); launch shapes are the library's own business here.
+  std::string SimulateGPU(int blocksize = 32) {
+    (void)blocksize;
+    return SimulateMI355X();
+  }
+
   // The MI355X path.  Observable effects are those of the reference's SimulateGPU()
   // (ref: particle_simulation_GPU.cu:277-303): out_put_data_[0] = initial data with
   // a = 0, t = 0; out_put_data_[k] = state after big step k with a = G*sum, m, and

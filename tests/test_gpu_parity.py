@@ -534,3 +534,22 @@ def test_tiny_systems_one_launch_per_big_step(n):
         _, b = gpu_simulate(p, m, 1, 50, 1e-3, eps2=1e-3, integrator=nb.KICK_DRIFT, variant=7)
         assert rel_pos_err(a[0, :, :3], b[0, :, :3]) <= 1e-13
         assert vec_rel(a[0, :, 3:6], b[0, :, 3:6]) <= 1e-12
+
+
+@pytest.mark.parametrize("n", [40, 300, 3000, 9000])
+def test_nan_input_spreads_as_in_the_reference(n):
+    """Garbage in, the reference's garbage out: `r_squared != 0` is true for NaN (ref:
+    particle_simulation.h:269, particle_simulation_GPU.cu:92), so one body with a NaN velocity
+    (the reference's own saturn_ring.cu scene produces one: a negative ring radius under a
+    sqrt, particle_initializer.h:130) has a NaN position after one small step and has made
+    every body NaN after two more.  Every kernel family (one wave, wave per body, pair-symmetric)
+    must show the oracle's pattern step by step -- neither mask the NaN nor crash."""
+    p, m = nb.ic_plummer(n, 11)
+    p[n // 3, 3] = np.nan
+    for steps in (1, 2, 3):
+        _, ref = ol.simulate(p, m, 1, steps, 1e-3, threads=8)
+        _, out = gpu_simulate(p, m, 1, steps, 1e-3)
+        assert np.array_equal(np.isnan(out[0]), np.isnan(ref[0])), steps
+        ok = ~np.isnan(ref[0])
+        np.testing.assert_allclose(out[0][ok], ref[0][ok], rtol=1e-10, atol=1e-300)
+    assert np.isnan(out[0][:, :6]).all()   # after three small steps: everything

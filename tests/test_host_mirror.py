@@ -266,3 +266,42 @@ def test_reference_saturn_ring_main_on_the_gpu(tmp_path):
     assert last.shape == (500, 11) and np.isfinite(last).all()
     radius = np.linalg.norm(last[1:, 1:4], axis=1)
     assert 2e7 < radius.min() and radius.max() < 5e8    # still a ring after one day
+
+
+@pytest.mark.gpu
+def test_reference_gpu_scene_main_runs_through_simulate_gpu(tmp_path):
+    """The reference's GPU scene, saturn_ring.cu, with the one line its user changes (the
+    `#include "particle_simulation_GPU.cu"` becomes this repository's particle_simulation.h; built
+    by `make -C oracle ref-scenes`): its own `my_sim.SimulateGPU(32)` call now runs the MI355X
+    path -- N = 2000, 500 big steps x 6480 small steps as its author set it up."""
+    exe = REPO / "oracle" / "_ref" / "saturn_ring_cu_main"
+    if not exe.exists():
+        pytest.skip("oracle/_ref/saturn_ring_cu_main not built (needs the reference mounted at build time)")
+    need_cli()
+    a, b = tmp_path / "cu_main", tmp_path / "cli"
+    a.mkdir(); b.mkdir()
+    r = subprocess.run([str(exe)], cwd=a, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    assert "Simulation on MI355X succesfull." in r.stdout
+    files = sorted(f.name for f in a.glob("N_Body_Timestep_*.txt"))
+    assert len(files) == 501
+    # same recipe and seed as saturn_ring.cc, four times the bodies: the first 500 rows of
+    # snapshot 0 are the driver's N = 500 scene
+    r = subprocess.run([str(CLI), "demo", "saturn_ring", "mi355x", "1", "1000", str(b) + "/"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    assert (a / files[0]).read_bytes().splitlines()[:500] == (b / files[0]).read_bytes().splitlines()
+    first = np.loadtxt(a / files[0])
+    last = np.loadtxt(a / files[-1])
+    assert first.shape == last.shape == (2000, 11)
+    assert last[0, 0] == pytest.approx(64800.0)          # t of the last snapshot: 18 hours
+    # The scene as the reference's author wrote it is broken at this N and seed: body 1779 draws a
+    # NEGATIVE ring radius (1.12e8 + N(0, 3e7) = -2.1e6), NonCircularOrbitMoon takes
+    # sqrt(G M / R) of it (ref: particle_initializer.h:130) and hands the simulation a NaN
+    # velocity.  `r_squared != 0` is true for NaN (ref: particle_simulation_GPU.cu:92), so the
+    # reference's own kernel spreads it to every body within two small steps.  The drop-in
+    # must do exactly the same -- not mask it, not crash:
+    bad = np.nonzero(~np.isfinite(first[:, 4:7]).all(axis=1))[0]
+    assert list(bad) == [1779] and first[1779, 1:4].tolist() != [0, 0, 0] and np.isfinite(first[1779, 1:4]).all()
+    assert np.isnan(last[:, 1:10]).all()                 # r, v, a of every body
+    assert np.array_equal(last[:, 10], first[:, 10]) and np.isfinite(last[:, 10]).all()   # masses untouched

@@ -64,3 +64,6 @@ def test_one_line_swap_to_simulate_mi355x_builds():
     r = subprocess.run(["make", "-C", str(REPO / "oracle"), "ref-scenes"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "built _ref/saturn_ring_mi355x" in r.stdout, r.stdout + r.stderr
     assert "warning" not in r.stderr, r.stderr
+    # ... and the reference's GPU scene (saturn_ring.cu; only its #include of the CUDA definitions
+    # changes, its SimulateGPU(32) call stays) is built by the same target
+    assert (REFDIR / "saturn_ring_cu_main").exists()
