@@ -165,8 +165,8 @@ def _rank_main(rank, world, port, n, steps, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n,expect_sym", [(1500, False), (20000, True)])
-def test_two_real_ranks_end_to_end(n, expect_sym):
+@pytest.mark.parametrize("n,expect_sym,world", [(1500, False, 2), (20000, True, 2), (70000, True, 4)])
+def test_two_real_ranks_end_to_end(n, expect_sym, world):
     """ShardedNBody.step() as bench.py drives it -- collectives, buffer rotation, overlap
     split (one-sided) and partial-sum exchange (pair-symmetric) -- against the oracle."""
     import socket
@@ -174,7 +174,7 @@ def test_two_real_ranks_end_to_end(n, expect_sym):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    world, steps = 2, 5
+    steps = 5
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_rank_main, args=(r, world, port, n, steps, q)) for r in range(world)]
