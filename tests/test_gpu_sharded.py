@@ -117,6 +117,41 @@ def test_symmetric_multi_slab_equals_oracle(world, n):
     assert (num / np.linalg.norm(out[0, :, 6:9], axis=1)).max() <= 1e-12
 
 
+def test_config4_one_gpu_vs_eight_ranks_agree():
+    """BASELINE config 4 (Plummer N = 1 048 576 over 8 ranks), SURVEY 8d: 'parity by ... 1-GPU vs
+    P-GPU position agreement <= 1e-12'.  The eight ranks' kernels run one after the other on the
+    one GPU of the test box (same slab layout and launches as under bench.py --gpus 8, the two
+    collectives done by hand); the single-GPU run is the handle API.  Two small steps: the second
+    one works on positions that went through the exchange."""
+    n, world, steps = 1048576, 8, 2
+    p, m = nb.ic_plummer(n, 42)
+    with nb.Simulation(n, 1e-3) as one:
+        one.upload(p, m)
+        ref = one.run(steps, snapshot=True)
+    sims = [ShardedNBody(p, m, 1e-3, rank=r, world=world, device="cuda") for r in range(world)]
+    assert all(s.workspace is not None and s.acc_all is not None for s in sims)
+    grp = LoopbackGroup(sims)
+    for k in range(steps):
+        for s in sims:
+            s._common = dict(pos_cur=s.pos[s.cur], pos_next=s.pos[s.cur ^ 1], mass=s.mass, vel=s.vel, S=s.S,
+                             world=world, rank=s.rank, count=s.count, dt=s.dt, G=s.G, eps2=s.eps2)
+            s._sym_forces(s.pos[s.cur], s._common)
+        total = sum(s.acc_all for s in sims)
+        for s in sims:
+            s.acc.copy_(total[s.rank])
+            s._integrate(s._common, s.snap if k == steps - 1 else None)
+            s.cur ^= 1
+        del total
+        grp.exchange()
+    torch.cuda.synchronize()
+    snap = np.concatenate([s.own_snapshot() for s in sims])
+    assert rel_pos_err(snap[:, :3], ref[:, :3]) <= 1e-12
+    num = np.linalg.norm(snap[:, 6:9] - ref[:, 6:9], axis=1)
+    assert (num / np.linalg.norm(ref[:, 6:9], axis=1)).max() <= 1e-11   # sums of 1e6 terms in another order
+    num = np.linalg.norm(snap[:, 3:6] - ref[:, 3:6], axis=1)
+    assert (num / np.linalg.norm(ref[:, 3:6], axis=1)).max() <= 1e-12
+
+
 @pytest.mark.parametrize("variant", [nb.VARIANT_SYM4, nb.VARIANT_SYM8])
 def test_symmetric_phases_equal_whole(variant):
     """phase 1 (diagonal tiles, own slab only) + phase 2 (the rest) == phase 0."""
