@@ -296,13 +296,15 @@ __global__ __launch_bounds__(256) void sym_tiles_kernel(const SymArgs a) {
   if (tid == 0) m_row = mi[0];
   __syncthreads();
   const T m_ref = m_row;
-  bool row_same = (m_ref != 0) && (m_ref - m_ref == 0);  // not 0, inf or NaN
+  // not 0, inf or NaN -- nor so small that 1 / m_ref (kRowUnit) overflows
+  const T inv_probe = 1 / m_ref;
+  bool row_same = (m_ref != 0) && (m_ref - m_ref == 0) && (inv_probe - inv_probe == 0);
 #pragma unroll
   for (int k = 0; k < IPT; k++) row_same = row_same && (mi[k] == m_ref);
   const bool row_uniform = __syncthreads_and(row_same) && !a.no_eq;
   // double: a uniform row keeps its i sums in units of 1/m_ref (kDeferred / kRowUnit)
   constexpr bool kDouble = sizeof(T) == sizeof(double);
-  const T inv_m_ref = row_uniform ? 1 / m_ref : 0;
+  const T inv_m_ref = row_uniform ? inv_probe : 0;
 
   // distances [d_lo, d_hi] cut into dsplit chunks whose sizes differ by at most one
   const int nd = a.d_hi - a.d_lo + 1;
