@@ -7,6 +7,9 @@
 namespace nbody_internal {
 // Text behind nbody_mi355x_last_error() (thread-local).
 void set_error(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
+// nbody_kernels.hip: host-side shape checks of a step's arguments -- everything the kernels'
+// indexing assumes, verified before any launch
+int check_step_args(const nbody_mi355x_step_args* a);
 // nbody_sym.hip: pair-symmetric step (args already validated by check_step_args)
 bool sym_supported(const nbody_mi355x_step_args& a, int64_t* preferred_bytes, int64_t* least_bytes);
 int sym_step(const nbody_mi355x_step_args& a, struct ihipStream_t* stream);

@@ -564,7 +564,7 @@ static constexpr int64_t kSymMinBodies = 2048;
 
 // Host-side shape checks: everything the kernel's indexing assumes is verified
 // here, before any launch.
-static int check_step_args(const nbody_mi355x_step_args* a) {
+int nbody_internal::check_step_args(const nbody_mi355x_step_args* a) {
   if (!a) { set_error("step: null args"); return NBODY_MI355X_ERR_INVALID; }
   if (!a->pos_cur || !a->mass) { set_error("step: null pos_cur/mass"); return NBODY_MI355X_ERR_INVALID; }
   if (a->shard_slots <= 0 || a->shard_slots % kTile != 0) {
@@ -615,7 +615,7 @@ static bool is_sym_variant(int v) {
 }
 
 extern "C" int nbody_mi355x_step_f64(const nbody_mi355x_step_args* args, void* stream) {
-  int rc = check_step_args(args);
+  int rc = nbody_internal::check_step_args(args);
   if (rc != NBODY_MI355X_OK) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
   hipError_t e;
@@ -635,7 +635,11 @@ extern "C" int nbody_mi355x_step_f64(const nbody_mi355x_step_args* args, void* s
   }
   if (args->variant == 0 && wave_size) {
     e = launch_wave(*args, s);
-  } else if (args->precision == NBODY_MI355X_FP32) {
+  } else if (args->precision == NBODY_MI355X_FP32 &&
+             !(args->acc_in != nullptr && args->j0_begin == args->j0_end && args->j1_begin == args->j1_end)) {
+    // (a step with acc_in and no j range only integrates sums that were reduced in double:
+    // it takes the double build whatever the precision, as the one-slab finish kernel does --
+    // narrowing them first would make 1-shard and N-shard FP32 runs differ for nothing)
     switch (args->variant) {
       case 1: e = launch_step<1, float, 8>(*args, s); break;
       case 4: e = launch_step<4, float, 4>(*args, s); break;

@@ -257,6 +257,50 @@ __device__ __forceinline__ void block_base(const SymArgs& a, int J, const double
   *m = a.mass + static_cast<int64_t>(slab) * a.S + off;
 }
 
+// FP32 variant: where a row's coordinates are measured from.  A float holds a coordinate to
+// 6e-8 of its MAGNITUDE, so narrowing absolute positions makes close pairs of a system that
+// sits far from the origin cancel (a cluster of size 1 at distance 2e3: ulp 1.2e-4).  The
+// reference's float instantiation differences full-precision inputs (particle_simulation.h:
+// 257-270); here the row's bodies and every j body staged against them are taken relative
+// to one point, in double, and only the (small) relative coordinate is narrowed.  The point
+// is the centroid of the row's real bodies -- for bodies in no spatial order that is the
+// system's centre, for sorted ones the block's own neighbourhood.  Padding slots (mass 0 at
+// the origin) are not counted; a centroid that is not finite (NaN / inf input) falls back to
+// 0, i.e. absolute coordinates, so that garbage spreads exactly as before.  Every workgroup
+// of a row adds in the same fixed order: the same origin, bit for bit, run to run.
+template <int IPT>
+__device__ __forceinline__ void row_origin(const double* px, const double* pm, int64_t S, int tid, double* ox,
+                                           double* oy, double* oz) {
+  __shared__ double cen[4][4];
+  double sx = 0.0, sy = 0.0, sz = 0.0, cnt = 0.0;
+#pragma unroll
+  for (int k = 0; k < IPT; k++) {
+    const int idx = k * 256 + tid;
+    const double x = px[idx], y = px[S + idx], z = px[2 * S + idx];
+    const bool padding = pm[idx] == 0.0 && x == 0.0 && y == 0.0 && z == 0.0;
+    sx += x; sy += y; sz += z;
+    cnt += padding ? 0.0 : 1.0;
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    sx += __shfl_down(sx, o, 64);
+    sy += __shfl_down(sy, o, 64);
+    sz += __shfl_down(sz, o, 64);
+    cnt += __shfl_down(cnt, o, 64);
+  }
+  if ((tid & 63) == 0) {
+    cen[tid >> 6][0] = sx; cen[tid >> 6][1] = sy; cen[tid >> 6][2] = sz; cen[tid >> 6][3] = cnt;
+  }
+  __syncthreads();
+  const double n = cen[0][3] + cen[1][3] + cen[2][3] + cen[3][3];
+  const double cx = (cen[0][0] + cen[1][0] + cen[2][0] + cen[3][0]) / n;
+  const double cy = (cen[0][1] + cen[1][1] + cen[2][1] + cen[3][1]) / n;
+  const double cz = (cen[0][2] + cen[1][2] + cen[2][2] + cen[3][2]) / n;
+  const bool ok = n > 0.0 && (cx - cx == 0.0) && (cy - cy == 0.0) && (cz - cz == 0.0);
+  *ox = ok ? cx : 0.0;
+  *oy = ok ? cy : 0.0;
+  *oz = ok ? cz : 0.0;
+}
+
 template <int IPT, typename T>
 __global__ __launch_bounds__(256) void sym_tiles_kernel(const SymArgs a) {
   constexpr int B = 256 * IPT;
@@ -278,15 +322,25 @@ __global__ __launch_bounds__(256) void sym_tiles_kernel(const SymArgs a) {
   asm volatile("" : "+v"(c15), "+v"(c1875));
 
   T xi[IPT], yi[IPT], zi[IPT], mi[IPT], ax[IPT], ay[IPT], az[IPT];
+  // float only: the origin the row's and the staged bodies' coordinates are taken relative
+  // to BEFORE they are narrowed (row_origin); 0 in double, where nothing is subtracted
+  double ox = 0.0, oy = 0.0, oz = 0.0;
   {
     const double *px, *pm;
     block_base<B>(a, I, &px, &pm);
+    if constexpr (sizeof(T) == sizeof(float)) row_origin<IPT>(px, pm, S, tid, &ox, &oy, &oz);
 #pragma unroll
     for (int k = 0; k < IPT; k++) {
       const int idx = k * 256 + tid;
-      xi[k] = static_cast<T>(px[idx]);
-      yi[k] = static_cast<T>(px[S + idx]);
-      zi[k] = static_cast<T>(px[2 * S + idx]);
+      if constexpr (sizeof(T) == sizeof(float)) {
+        xi[k] = static_cast<T>(px[idx] - ox);
+        yi[k] = static_cast<T>(px[S + idx] - oy);
+        zi[k] = static_cast<T>(px[2 * S + idx] - oz);
+      } else {
+        xi[k] = static_cast<T>(px[idx]);
+        yi[k] = static_cast<T>(px[S + idx]);
+        zi[k] = static_cast<T>(px[2 * S + idx]);
+      }
       mi[k] = static_cast<T>(pm[idx]);
       ax[k] = ay[k] = az[k] = 0;
     }
@@ -329,8 +383,14 @@ __global__ __launch_bounds__(256) void sym_tiles_kernel(const SymArgs a) {
       for (int o = tid; o < j_n; o += 256) {
         const int idx = j_lo + o;
         const int e = o & 63, q = (o >> 6) * kGrp + e;
-        const P2<T> vxy{static_cast<T>(px[idx]), static_cast<T>(px[S + idx])};
-        const P2<T> vzm{static_cast<T>(px[2 * S + idx]), static_cast<T>(pm[idx])};
+        P2<T> vxy, vzm;
+        if constexpr (sizeof(T) == sizeof(float)) {  // relative to the row's origin, narrowed after
+          vxy = P2<T>{static_cast<T>(px[idx] - ox), static_cast<T>(px[S + idx] - oy)};
+          vzm = P2<T>{static_cast<T>(px[2 * S + idx] - oz), static_cast<T>(pm[idx])};
+        } else {
+          vxy = P2<T>{static_cast<T>(px[idx]), static_cast<T>(px[S + idx])};
+          vzm = P2<T>{static_cast<T>(px[2 * S + idx]), static_cast<T>(pm[idx])};
+        }
         fill_same = fill_same && (vzm.b == m_ref);
         xy[q] = vxy;
         zm[q] = vzm;
@@ -720,3 +780,4 @@ int sym_step(const nbody_mi355x_step_args& a, hipStream_t stream) {
 }
 
 }  // namespace nbody_internal
+

@@ -331,3 +331,24 @@ def test_symmetric_workspace_too_small_is_an_error():
                        count=s.count, dt=s.dt, G=s.G, eps2=0.0, acc_in=None, acc_out=None, snapshot=None,
                        ranges=((0, 20000), (0, 0)), workspace=s.workspace, variant=nb.VARIANT_SYM)
     assert e.value.code == nb.ERR_INVALID and "workspace" in str(e.value)
+
+
+def test_bench_self_launch_two_ranks_share_the_gpu():
+    """`python bench.py --gpus 2` with no launcher: the parent (which never touches the GPU)
+    starts the two rank processes itself and relays rank 0's line -- here as a rehearsal, both
+    ranks on the one GPU of the box, gloo staged through the host instead of RCCL."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+    repo = Path(__file__).resolve().parent.parent
+    r = subprocess.run([sys.executable, str(repo / "bench.py"), "--gpus", "2", "--share-devices", "--backend", "gloo",
+                        "--bodies", "131072", "--steps", "3", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=400)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["scaling"] == "strong"
+    assert line["config"]["bodies"] == 131072 and line["value"] > 0
+    assert "cpu_baseline" not in line and "other_configs" not in line     # N = 1 only
