@@ -268,6 +268,10 @@ __device__ __forceinline__ void block_base(const SymArgs& a, int J, const double
 // the origin) are not counted; a centroid that is not finite (NaN / inf input) falls back to
 // 0, i.e. absolute coordinates, so that garbage spreads exactly as before.  Every workgroup
 // of a row adds in the same fixed order: the same origin, bit for bit, run to run.
+__device__ __forceinline__ double uniform(double v) {  // a wave-uniform value into SGPRs
+  return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)),
+                          __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
 template <int IPT>
 __device__ __forceinline__ void row_origin(const double* px, const double* pm, int64_t S, int tid, double* ox,
                                            double* oy, double* oz) {
@@ -296,9 +300,11 @@ __device__ __forceinline__ void row_origin(const double* px, const double* pm, i
   const double cy = (cen[0][1] + cen[1][1] + cen[2][1] + cen[3][1]) / n;
   const double cz = (cen[0][2] + cen[1][2] + cen[2][2] + cen[3][2]) / n;
   const bool ok = n > 0.0 && (cx - cx == 0.0) && (cy - cy == 0.0) && (cz - cz == 0.0);
-  *ox = ok ? cx : 0.0;
-  *oy = ok ? cy : 0.0;
-  *oz = ok ? cz : 0.0;
+  // workgroup-uniform: kept in scalar registers (the float IPT = 4 build sits at the VGPR
+  // count that still allows two waves per SIMD; six more VGPRs halve its occupancy)
+  *ox = uniform(ok ? cx : 0.0);
+  *oy = uniform(ok ? cy : 0.0);
+  *oz = uniform(ok ? cz : 0.0);
 }
 
 template <int IPT, typename T>
