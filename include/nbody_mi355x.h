@@ -155,6 +155,26 @@ int nbody_mi355x_step_f64(const nbody_mi355x_step_args* args, void* stream);
  * different summation order, bit-reproducible.  No counterpart in the reference. */
 int nbody_mi355x_step_workspace_bytes(const nbody_mi355x_step_args* args, int64_t* bytes);
 
+/* The same small step for callers that cannot allocate device memory: code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc.  It has NO counterpart in
+ * the reference (whose GPU path allocates per run, particle_simulation_GPU.cu:13-35).  It is
+ * nbody_mi355x_step_f64 restricted to the pair-symmetric kernels (variant 0 or
+ * NBODY_MI355X_VARIANT_SYM*), with their partial-sum workspace in a device array that is part
+ * of the library's code object -- NBODY_MI355X_STATIC_SCRATCH_BYTES on every GPU the library
+ * runs on, held until the process ends.  args->workspace / workspace_bytes are ignored.
+ * It calls no hipMalloc / hipFree or any other allocating routine.  Layouts whose MINIMUM
+ * workspace exceeds the array (about 75 000 bodies on one slab) are rejected with
+ * NBODY_MI355X_ERR_INVALID and a text that names the size needed; so are one-sided variants
+ * (they need no scratch: call nbody_mi355x_step_f64) and layouts the pair-symmetric kernels
+ * do not apply to (fewer than two 256-slot blocks).  Results are bit-identical to
+ * nbody_mi355x_step_f64 given a workspace of NBODY_MI355X_STATIC_SCRATCH_BYTES.
+ * All calls on one GPU share that GPU's array: calls that overlap on one GPU (two streams,
+ * two host threads) race -- serialise them.  Nothing in the array needs clearing between
+ * calls.  The first call on each device resolves the array's address there
+ * (hipGetSymbolAddress): make it outside of graph capture. */
+#define NBODY_MI355X_STATIC_SCRATCH_BYTES 134217728 /* 128 MiB */
+int nbody_mi355x_step_f64_static(const nbody_mi355x_step_args* args, void* stream);
+
 /* Particle<double>[count] AoS {r[3], v[3]} (ref: particle_simulation.h:20-24)
  * on the device -> own slab's pos (x,y,z runs) + vel, and back.  These are the
  * layout converters either side of the step kernel. */

@@ -46,6 +46,7 @@
 
 #include <cstdint>
 #include <cstdlib>
+#include <mutex>
 
 #include "nbody_device.hpp"
 #include "nbody_internal.h"
@@ -787,3 +788,77 @@ int sym_step(const nbody_mi355x_step_args& a, hipStream_t stream) {
 
 }  // namespace nbody_internal
 
+// ------------------------------------------------------------------ no allocation
+// nbody_mi355x_step_f64_static: the pair-symmetric small step for callers that cannot
+// allocate (code under HIP graph capture, tight serving loops, harnesses that forbid
+// hipMalloc).  The partial-sum workspace is this file-scope device array; every GPU the
+// library's code is loaded on holds its own copy, at its own address, until the process ends.
+// In host code the array's NAME is only a handle for hipGetSymbolAddress -- the address a
+// kernel can use is what that call returns, once per device, with that device current.
+static __device__ __align__(256) unsigned char scratch[NBODY_MI355X_STATIC_SCRATCH_BYTES];
+
+namespace {
+constexpr int kMaxStaticDevices = 64;
+std::mutex g_static_mutex;
+void* g_static_ptr[kMaxStaticDevices];  // per device: where `scratch` lives there (nullptr: not yet asked)
+
+// the current device's copy of `scratch` (resolved on the first call on that device)
+int static_scratch(void** ptr) {
+  int dev = -1;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess || dev < 0 || dev >= kMaxStaticDevices) {
+    (void)hipGetLastError();
+    set_error("step_f64_static: no current device (%s)", e != hipSuccess ? hipGetErrorString(e) : "ordinal out of range");
+    return NBODY_MI355X_ERR_NO_DEVICE;
+  }
+  std::lock_guard<std::mutex> lock(g_static_mutex);
+  if (g_static_ptr[dev] == nullptr) {
+    void* p = nullptr;
+    e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+    if (e != hipSuccess || p == nullptr) {
+      (void)hipGetLastError();
+      set_error("step_f64_static: hipGetSymbolAddress on device %d: %s", dev, hipGetErrorString(e));
+      return NBODY_MI355X_ERR_NO_DEVICE;
+    }
+    g_static_ptr[dev] = p;
+  }
+  *ptr = g_static_ptr[dev];
+  return NBODY_MI355X_OK;
+}
+}  // namespace
+
+extern "C" int nbody_mi355x_step_f64_static(const nbody_mi355x_step_args* args, void* stream) {
+  int rc = nbody_internal::check_step_args(args);
+  if (rc != NBODY_MI355X_OK) return rc;
+  nbody_mi355x_step_args a = *args;
+  const bool sym_variant = a.variant == NBODY_MI355X_VARIANT_SYM || a.variant == NBODY_MI355X_VARIANT_SYM1 ||
+                           a.variant == NBODY_MI355X_VARIANT_SYM2 || a.variant == NBODY_MI355X_VARIANT_SYM4 ||
+                           a.variant == NBODY_MI355X_VARIANT_SYM8;
+  if (a.variant != 0 && !sym_variant) {
+    set_error("step_f64_static: variant %d is a one-sided kernel, which needs no scratch: call nbody_mi355x_step_f64",
+              a.variant);
+    return NBODY_MI355X_ERR_INVALID;
+  }
+  if (!sym_variant) a.variant = NBODY_MI355X_VARIANT_SYM;
+  int64_t preferred = 0, least = 0;
+  if (!nbody_internal::sym_supported(a, &preferred, &least)) {
+    set_error("step_f64_static: the pair-symmetric step does not apply to %d slab(s) of %lld slots "
+              "(at least two blocks of 256 slots are needed)", a.num_shards, (long long)a.shard_slots);
+    return NBODY_MI355X_ERR_INVALID;
+  }
+  if (least > static_cast<int64_t>(NBODY_MI355X_STATIC_SCRATCH_BYTES)) {
+    set_error("step_f64_static: %d slab(s) of %lld slots need a workspace of at least %lld bytes; the static "
+              "scratch holds %lld (NBODY_MI355X_STATIC_SCRATCH_BYTES): use nbody_mi355x_step_f64 with a workspace",
+              a.num_shards, (long long)a.shard_slots, (long long)least, (long long)NBODY_MI355X_STATIC_SCRATCH_BYTES);
+    return NBODY_MI355X_ERR_INVALID;
+  }
+  void* ptr = nullptr;
+  rc = static_scratch(&ptr);
+  if (rc != NBODY_MI355X_OK) return rc;
+  // Nothing in the workspace has to start at zero: every R chunk, C row and accumulator entry
+  // the finishing kernels read is stored by a kernel of THIS call first (launch()), so what
+  // the previous call -- of any size -- left behind is never seen.
+  a.workspace = ptr;
+  a.workspace_bytes = static_cast<int64_t>(NBODY_MI355X_STATIC_SCRATCH_BYTES);
+  return nbody_internal::sym_step(a, static_cast<hipStream_t>(stream));
+}

@@ -53,6 +53,7 @@ class StepArgs(C.Structure):
 
 
 VARIANT_WAVE, VARIANT_TINY = 7, 8
+STATIC_SCRATCH_BYTES = 134217728   # NBODY_MI355X_STATIC_SCRATCH_BYTES
 WAVE_MAX_BODIES = 7168   # NBODY_MI355X_WAVE_MAX_BODIES: below, whole FP64 steps take the wave kernels
 VARIANT_SYM, VARIANT_SYM1, VARIANT_SYM2, VARIANT_SYM4, VARIANT_SYM8 = 10, 11, 12, 14, 18
 
@@ -73,6 +74,7 @@ SYMBOLS = {
     "nbody_mi355x_last_error": (C.c_char_p, []),
     "nbody_mi355x_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "nbody_mi355x_step_f64": (C.c_int, [C.POINTER(StepArgs), _P]),
+    "nbody_mi355x_step_f64_static": (C.c_int, [C.POINTER(StepArgs), _P]),
     "nbody_mi355x_step_workspace_bytes": (C.c_int, [C.POINTER(StepArgs), C.POINTER(C.c_int64)]),
     "nbody_mi355x_pack_f64": (C.c_int, [_P, C.c_int64, _P, _P, C.c_int64, _P]),
     "nbody_mi355x_unpack_f64": (C.c_int, [_P, _P, C.c_int64, C.c_int64, _P, _P]),

@@ -1,0 +1,102 @@
+"""nbody_mi355x_step_f64_static -- the one entry point that allocates nothing (its workspace is
+a device array inside the library, include/nbody_mi355x.h) -- against nbody_mi355x_step_f64
+on the same inputs, through the C ABI.  Same kernels, same launch plan, same number of
+workspace rows: the outputs must agree bit for bit; and against the oracle to the FP64 bar.
+Two calls in a row, the second on a smaller system (the array keeps the first call's
+contents: nothing of them may leak into the second result).  Collected last on purpose."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import nbody_mi355x as nb
+import oracle_lib as ol
+from conftest import rel_pos_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _slab(p, m, S, dev):
+    import torch
+    n = p.shape[0]
+    pos = np.zeros((3, S))
+    pos[:, :n] = p[:, :3].T
+    vel = np.zeros((3, S))
+    vel[:, :n] = p[:, 3:].T
+    mass = np.zeros(S)
+    mass[:n] = m
+    t = lambda a: torch.from_numpy(a).to(dev)
+    return t(pos), t(vel), t(mass)
+
+
+def _one_step(entry, p, m, dt, *, workspace, precision=nb.FP64):
+    """One small step with snapshot through `entry` ("static" or "workspace")."""
+    import torch
+    dev = torch.device("cuda", 0)
+    n = p.shape[0]
+    S = nb.round_up(n, 2048 if n >= 65536 else (1024 if n >= 8192 else nb.TILE))
+    pos, vel, mass = _slab(p, m, S, dev)
+    nxt = torch.zeros_like(pos)
+    snap = torch.full((n, 9), np.nan, dtype=torch.float64, device=dev)
+    a = nb.StepArgs()
+    a.pos_cur, a.pos_next, a.mass, a.vel = pos.data_ptr(), nxt.data_ptr(), mass.data_ptr(), vel.data_ptr()
+    a.snapshot = snap.data_ptr()
+    a.shard_slots, a.num_shards, a.own_shard, a.own_count = S, 1, 0, n
+    a.j0_begin, a.j0_end = 0, n
+    a.dt, a.G, a.eps2 = dt, nb.G_REFERENCE, 0.0
+    a.precision, a.variant = precision, nb.VARIANT_SYM
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    L = nb.lib()
+    if entry == "static":
+        a.workspace, a.workspace_bytes = None, 0
+        nb.check(L.nbody_mi355x_step_f64_static(C.byref(a), stream))
+    else:
+        a.workspace, a.workspace_bytes = workspace.data_ptr(), workspace.numel() * 8
+        nb.check(L.nbody_mi355x_step_f64(C.byref(a), stream))
+    torch.cuda.synchronize(dev)
+    return nxt.cpu().numpy(), vel.cpu().numpy(), snap.cpu().numpy()
+
+
+@pytest.mark.parametrize("precision", ["fp64", "fp32"])
+def test_static_entry_point_matches_the_allocating_one(precision):
+    import torch
+    dev = torch.device("cuda", 0)
+    prec = nb.FP64 if precision == "fp64" else nb.FP32
+    # the allocating entry point gets a workspace of exactly the static array's size: the same
+    # number of rows -> the same batching of the distances -> the same order of additions
+    ws = torch.empty(nb.STATIC_SCRATCH_BYTES // 8, dtype=torch.float64, device=dev)
+    rng = np.random.default_rng(3)
+    for n in (30000, 9000):                       # the second call is the smaller one
+        p, m = nb.ic_plummer(n, 500 + n)
+        m = m * rng.uniform(0.5, 2.0, n)
+        ws.fill_(float("nan"))                    # (what the other entry point starts from must not matter either)
+        ref = _one_step("workspace", p, m, 1e-3, workspace=ws, precision=prec)
+        got = _one_step("static", p, m, 1e-3, workspace=None, precision=prec)
+        for r, g in zip(ref, got):
+            assert np.array_equal(r, g)
+        _, orc = ol.simulate(p, m, 1, 1, 1e-3, threads=16)
+        snap = got[2]
+        assert np.all(np.isfinite(snap))
+        tol_r, tol_a = (1e-14, 1e-12) if precision == "fp64" else (1e-9, 1e-4)
+        assert rel_pos_err(snap[:, :3], orc[0, :, :3]) <= tol_r
+        scale = np.linalg.norm(orc[0, :, 6:9], axis=1).max()
+        assert np.abs(snap[:, 6:9] - orc[0, :, 6:9]).max() <= tol_a * scale
+
+
+def test_static_entry_point_rejects_what_does_not_fit():
+    import torch
+    dev = torch.device("cuda", 0)
+    L = nb.lib()
+    a = nb.StepArgs()
+    S = 1 << 20                                   # minimum workspace far beyond 128 MiB
+    buf = torch.zeros(8, dtype=torch.float64, device=dev)   # never dereferenced: rejected before any launch
+    a.pos_cur, a.pos_next, a.mass, a.vel = buf.data_ptr(), buf.data_ptr() + 8, buf.data_ptr(), buf.data_ptr()
+    a.shard_slots, a.num_shards, a.own_shard, a.own_count = S, 1, 0, S
+    a.j0_end = S
+    a.dt, a.G = 1e-3, nb.G_REFERENCE
+    assert L.nbody_mi355x_step_f64_static(C.byref(a), None) == nb.ERR_INVALID
+    assert "static" in nb.last_error() and "bytes" in nb.last_error()
+    a.shard_slots = a.own_count = a.j0_end = 4096
+    a.variant = 2                                 # a one-sided kernel: nothing to do with the scratch
+    assert L.nbody_mi355x_step_f64_static(C.byref(a), None) == nb.ERR_INVALID
+    assert "one-sided" in nb.last_error()
