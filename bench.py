@@ -340,7 +340,7 @@ def main():
                 traffic = json.loads(tf.read_text()).get(f"n{n}_{args.precision}")
             except Exception:
                 traffic = None
-        uses_sym = sim.workspace is not None and args.variant in (0, 10, 11, 12, 14, 18) and not (
+        uses_sym = sim.workspace is not None and args.variant in (0,) + nb.SYM_VARIANTS and not (
             args.variant == 0 and world == 1 and prec == nb.FP64 and n <= nb.WAVE_MAX_BODIES)
         kernel_label = ("pair-symmetric tiles + finish" if uses_sym else
                         "one-sided step_wave_kernel" if (world == 1 and prec == nb.FP64 and n <= nb.WAVE_MAX_BODIES

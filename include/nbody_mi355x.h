@@ -129,7 +129,7 @@ typedef struct {
 
 #define NBODY_MI355X_VARIANT_WAVE  7 /* one-sided, a wave per 1, 2 or 4 bodies: the default for whole
                                         FP64 steps over at most NBODY_MI355X_WAVE_MAX_BODIES slots */
-#define NBODY_MI355X_WAVE_MAX_BODIES 7168
+#define NBODY_MI355X_WAVE_MAX_BODIES 4096
 #define NBODY_MI355X_VARIANT_TINY  8 /* handle API only, at most 64 bodies: a whole big step in
                                         one launch of one wave (the default there); variants
                                         1-7 keep one launch per small step */
@@ -138,6 +138,12 @@ typedef struct {
 #define NBODY_MI355X_VARIANT_SYM2 12 /* pair-symmetric, 512-body blocks  */
 #define NBODY_MI355X_VARIANT_SYM4 14 /* pair-symmetric, 1024-body blocks */
 #define NBODY_MI355X_VARIANT_SYM8 18 /* pair-symmetric, 2048-body blocks (FP64 only) */
+/* pair-symmetric with WAVE tiles (mid-size systems): a workgroup's 4 waves hold the same
+ * 64, 128, 256 or 512 bodies and each takes its own groups of 64 j bodies */
+#define NBODY_MI355X_VARIANT_SYMW1 21
+#define NBODY_MI355X_VARIANT_SYMW2 22
+#define NBODY_MI355X_VARIANT_SYMW4 24
+#define NBODY_MI355X_VARIANT_SYMW8 28 /* (FP64 only) */
 
 /* One small step (or one half of a split one) for the own slab's bodies:
  * a_i = sum_j m_j (r_j - r_i) / |r_j - r_i|^3 over the j ranges, then
@@ -146,6 +152,14 @@ typedef struct {
  * maths as MakeSmallStep, particle_simulation.h:248-322).  Asynchronous on
  * `stream` (a hipStream_t, NULL = the default stream). */
 int nbody_mi355x_step_f64(const nbody_mi355x_step_args* args, void* stream);
+
+/* Which kernel build nbody_mi355x_step_f64 runs for these args: *variant = a concrete
+ * NBODY_MI355X_VARIANT_* -- SYM1 .. SYM8 / SYMW1 .. SYMW8 (pair-symmetric, block size
+ * resolved), WAVE, or a one-sided build 1 .. 6.  Read-only, no launch.  With variant = 0 and
+ * workspace = NULL (or too small) the answer is a one-sided build: that is how a caller sees
+ * that the pair-symmetric kernels were NOT taken.  No counterpart in the reference (one
+ * kernel, particle_simulation_GPU.cu:60). */
+int nbody_mi355x_step_variant(const nbody_mi355x_step_args* args, int32_t* variant);
 
 /* Scratch the pair-symmetric form of the step needs for these args (fields
  * shard_slots, num_shards, variant are read): *bytes = 0 if that form does not
@@ -163,7 +177,7 @@ int nbody_mi355x_step_workspace_bytes(const nbody_mi355x_step_args* args, int64_
  * of the library's code object -- NBODY_MI355X_STATIC_SCRATCH_BYTES on every GPU the library
  * runs on, held until the process ends.  args->workspace / workspace_bytes are ignored.
  * It calls no hipMalloc / hipFree or any other allocating routine.  Layouts whose MINIMUM
- * workspace exceeds the array (about 75 000 bodies on one slab) are rejected with
+ * workspace exceeds the array (about 180 000 bodies on one slab) are rejected with
  * NBODY_MI355X_ERR_INVALID and a text that names the size needed; so are one-sided variants
  * (they need no scratch: call nbody_mi355x_step_f64) and layouts the pair-symmetric kernels
  * do not apply to (fewer than two 256-slot blocks).  Results are bit-identical to
@@ -252,6 +266,12 @@ int nbody_mi355x_host_free(void* buffer);
 int nbody_mi355x_download(nbody_mi355x_sim* sim, void* particles);
 /* Total kinetic and potential energy of the current state. */
 int nbody_mi355x_energy(nbody_mi355x_sim* sim, double* ke, double* pe);
+/* Which kernel a small step of this handle runs (as nbody_mi355x_step_variant; TINY for the
+ * one-launch-per-big-step path) and the pair-symmetric workspace the handle holds, bytes
+ * (0: none -- then a system above NBODY_MI355X_WAVE_MAX_BODIES runs a one-sided kernel, at
+ * roughly half the rate: create() takes the workspace only if it fits in half of the free
+ * device memory).  On a multi-device handle: shard 0's.  No counterpart in the reference. */
+int nbody_mi355x_kernel_in_use(nbody_mi355x_sim* sim, int32_t* variant, int64_t* workspace_bytes);
 /* Device time (hipEvent) of the kernels of the last nbody_mi355x_run, seconds. */
 int nbody_mi355x_last_run_seconds(nbody_mi355x_sim* sim, double* seconds);
 

@@ -7,12 +7,42 @@
 namespace nbody_internal {
 // Text behind nbody_mi355x_last_error() (thread-local).
 void set_error(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
+// variants that name a pair-symmetric kernel build (workgroup tiles 10-18, wave tiles 21-28)
+inline bool is_sym_variant(int v) {
+  return v == NBODY_MI355X_VARIANT_SYM || v == NBODY_MI355X_VARIANT_SYM1 || v == NBODY_MI355X_VARIANT_SYM2 ||
+         v == NBODY_MI355X_VARIANT_SYM4 || v == NBODY_MI355X_VARIANT_SYM8 || v == NBODY_MI355X_VARIANT_SYMW1 ||
+         v == NBODY_MI355X_VARIANT_SYMW2 || v == NBODY_MI355X_VARIANT_SYMW4 || v == NBODY_MI355X_VARIANT_SYMW8;
+}
+// slots per block of a variant that pins one (0: the library chooses)
+inline int64_t block_of_variant(int v) {
+  switch (v) {
+    case NBODY_MI355X_VARIANT_SYM1: return 256;
+    case NBODY_MI355X_VARIANT_SYM2: return 512;
+    case NBODY_MI355X_VARIANT_SYM4: return 1024;
+    case NBODY_MI355X_VARIANT_SYM8: return 2048;
+    case NBODY_MI355X_VARIANT_SYMW1: return 64;
+    case NBODY_MI355X_VARIANT_SYMW2: return 128;
+    case NBODY_MI355X_VARIANT_SYMW4: return 256;
+    case NBODY_MI355X_VARIANT_SYMW8: return 512;
+    default: return 0;
+  }
+}
+// slots of a slab holding `bodies`: whole tiles, and whole blocks of the pair-symmetric kernels
+// the library would choose (large systems: 1024- or 2048-slot blocks; the padding is massless
+// bodies, <= 3 % more) or the variant pins
+inline int64_t slab_slots(int64_t bodies, int variant) {
+  int64_t unit = bodies >= 65536 ? 2048 : (bodies >= 8192 ? 1024 : NBODY_MI355X_TILE);
+  if (block_of_variant(variant) > unit) unit = block_of_variant(variant);
+  return (bodies + unit - 1) / unit * unit;
+}
 // nbody_kernels.hip: host-side shape checks of a step's arguments -- everything the kernels'
 // indexing assumes, verified before any launch
 int check_step_args(const nbody_mi355x_step_args* a);
 // nbody_sym.hip: pair-symmetric step (args already validated by check_step_args)
 bool sym_supported(const nbody_mi355x_step_args& a, int64_t* preferred_bytes, int64_t* least_bytes);
 int sym_step(const nbody_mi355x_step_args& a, struct ihipStream_t* stream);
+// the concrete variant (NBODY_MI355X_VARIANT_SYM1 .. SYMW8) the plan for these args resolves to, -1: none
+int sym_resolve(const nbody_mi355x_step_args& a);
 // nbody_kernels.hip: `substeps` whole small steps of a system of at most kTinyMaxBodies bodies
 // in ONE launch of one wave (in place on a.pos_cur / a.vel; a.snapshot, if set, receives the
 // last small step's records).  One slab, FP64, no split ranges.
@@ -27,4 +57,5 @@ int multi_enqueue(MultiSim* m, int64_t substeps, double* snapshot_out);
 int multi_wait(MultiSim* m, double* seconds);
 int multi_download(MultiSim* m, double* particles);
 int multi_energy(MultiSim* m, double* ke, double* pe);
+int multi_kernel_in_use(MultiSim* m, int32_t* variant, int64_t* workspace_bytes);
 }  // namespace nbody_internal

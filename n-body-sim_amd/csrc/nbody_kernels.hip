@@ -485,10 +485,11 @@ bool small_applies(const nbody_mi355x_step_args& a, int64_t max_bodies = 4096) {
 }
 
 // a wave per IPW bodies: whole steps over one j range of at most NBODY_MI355X_WAVE_MAX_BODIES
-// slots.  Shapes and thresholds from tools/sweep_small.py on MI355X (microseconds per small
-// step, graph-replayed; pair-symmetric kernels in brackets): 500 bodies 3.9, 1024 5.1 (42),
-// 2048 9.2 (43), 4096 20.1 (45), 6000 46.8 (56.5), 8192 60.3 (60.8) -- above ~7000 bodies the
-// pair-symmetric kernels' halved arithmetic outweighs their fixed cost of ~40 us per step.
+// slots.  Shapes and thresholds from tools/sweep_small.py and tools/sweep_mid.py on MI355X
+// (microseconds per small step, graph-replayed; pair-symmetric wave tiles in brackets):
+// 500 bodies 3.9, 1024 5.1, 2048 9.4 (11.4), 3072 16.6 (14.1), 4096 20.3 (19.2), 5120 39.8
+// (22.1), 6144 46.8 (33.9), 7168 53.7 (35.3) -- above ~4000 bodies the pair-symmetric kernels'
+// halved arithmetic outweighs their fixed cost (two launches, partial sums through HBM).
 constexpr int64_t kWaveMaxBodies = NBODY_MI355X_WAVE_MAX_BODIES;
 template <int JPL, int IPW>
 hipError_t launch_wave_t(const nbody_mi355x_step_args& a, hipStream_t stream) {
@@ -609,9 +610,51 @@ int nbody_internal::check_step_args(const nbody_mi355x_step_args* a) {
   return NBODY_MI355X_OK;
 }
 
-static bool is_sym_variant(int v) {
-  return v == NBODY_MI355X_VARIANT_SYM || v == NBODY_MI355X_VARIANT_SYM1 || v == NBODY_MI355X_VARIANT_SYM2 ||
-         v == NBODY_MI355X_VARIANT_SYM4 || v == NBODY_MI355X_VARIANT_SYM8;
+using nbody_internal::is_sym_variant;
+
+// Which kernel build a step with these (validated) args runs: a concrete variant code --
+// NBODY_MI355X_VARIANT_SYM1 .. SYMW8 (pair-symmetric, block size resolved), _WAVE, or a
+// one-sided build 1 .. 6.  The ONE place the choice is made: nbody_mi355x_step_f64 dispatches
+// on the result, nbody_mi355x_step_variant reports it.
+static int resolve_variant(const nbody_mi355x_step_args* args) {
+  if (is_sym_variant(args->variant)) return nbody_internal::sym_resolve(*args);  // (-1: does not apply)
+  const bool wave_size = small_applies(*args, kWaveMaxBodies) && args->j0_end - args->j0_begin <= kWaveMaxBodies;
+  if (args->variant == 0 && !wave_size && args->workspace != nullptr &&
+      args->acc_in == nullptr && args->acc_out == nullptr && args->own_count >= kSymMinBodies &&
+      args->j0_begin == 0 && args->j1_begin == args->j1_end &&
+      args->j0_end >= args->own_count) {
+    // default for large single-slab systems: the pair-symmetric kernels (DESIGN.md 3.1b)
+    nbody_mi355x_step_args a = *args;
+    a.variant = NBODY_MI355X_VARIANT_SYM;
+    // (any workspace from the plan's minimum up will do: fewer C rows mean more batches)
+    int64_t preferred = 0, least = 0;
+    if (nbody_internal::sym_supported(a, &preferred, &least) && least <= a.workspace_bytes)
+      return nbody_internal::sym_resolve(a);
+  }
+  if (wave_size && (args->variant == 0 || args->variant > 7)) return NBODY_MI355X_VARIANT_WAVE;
+  // a step with acc_in and no j range only integrates sums that were reduced in double: it
+  // takes a double build whatever the precision, as the one-slab finish kernel does --
+  // narrowing them first would make 1-shard and N-shard FP32 runs differ for nothing
+  const bool integrate_only = args->acc_in != nullptr && args->j0_begin == args->j0_end && args->j1_begin == args->j1_end;
+  if (args->precision == NBODY_MI355X_FP32 && !integrate_only)
+    return (args->variant == 1 || args->variant == 4) ? args->variant : 2;
+  if (args->variant >= 1 && args->variant <= 7) return args->variant;
+  // enough workgroups to give every SIMD >= 2 waves with 2 bodies per lane?
+  return args->own_count >= 2 * 256 * 4 * 2 * 64 ? 2 : 1;
+}
+
+extern "C" int nbody_mi355x_step_variant(const nbody_mi355x_step_args* args, int32_t* variant) {
+  if (!variant) { set_error("step_variant: null argument"); return NBODY_MI355X_ERR_INVALID; }
+  const int rc = nbody_internal::check_step_args(args);
+  if (rc != NBODY_MI355X_OK) return rc;
+  const int v = resolve_variant(args);
+  if (v < 0) {
+    set_error("step_variant: the pair-symmetric kernels of variant %d do not apply to %d slab(s) of %lld slots",
+              args->variant, args->num_shards, (long long)args->shard_slots);
+    return NBODY_MI355X_ERR_INVALID;
+  }
+  *variant = v;
+  return NBODY_MI355X_OK;
 }
 
 extern "C" int nbody_mi355x_step_f64(const nbody_mi355x_step_args* args, void* stream) {
@@ -619,47 +662,30 @@ extern "C" int nbody_mi355x_step_f64(const nbody_mi355x_step_args* args, void* s
   if (rc != NBODY_MI355X_OK) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
   hipError_t e;
-  if (is_sym_variant(args->variant)) return nbody_internal::sym_step(*args, s);
-  const bool wave_size = small_applies(*args, kWaveMaxBodies) && args->j0_end - args->j0_begin <= kWaveMaxBodies;
-  if (args->variant == 0 && !wave_size && args->workspace != nullptr &&
-      args->acc_in == nullptr && args->acc_out == nullptr && args->own_count >= kSymMinBodies &&
-      args->j0_begin == 0 && args->j1_begin == args->j1_end &&
-      args->j0_end >= args->own_count) {
-    // default for large single-slab systems: the pair-symmetric kernels (DESIGN.md 3.2)
+  const int v = resolve_variant(args);
+  if (v < 0 || is_sym_variant(v)) {
     nbody_mi355x_step_args a = *args;
-    a.variant = NBODY_MI355X_VARIANT_SYM;
-    // (any workspace from the plan's minimum up will do: fewer C rows mean more batches)
-    int64_t preferred = 0, least = 0;
-    if (nbody_internal::sym_supported(a, &preferred, &least) && least <= a.workspace_bytes)
-      return nbody_internal::sym_step(a, s);
+    if (v > 0) a.variant = v;
+    return nbody_internal::sym_step(a, s);  // (v < 0: reports why it does not apply)
   }
-  if (args->variant == 0 && wave_size) {
+  const bool fp32 = args->precision == NBODY_MI355X_FP32 &&
+                    !(args->acc_in != nullptr && args->j0_begin == args->j0_end && args->j1_begin == args->j1_end);
+  if (v == NBODY_MI355X_VARIANT_WAVE) {
     e = launch_wave(*args, s);
-  } else if (args->precision == NBODY_MI355X_FP32 &&
-             !(args->acc_in != nullptr && args->j0_begin == args->j0_end && args->j1_begin == args->j1_end)) {
-    // (a step with acc_in and no j range only integrates sums that were reduced in double:
-    // it takes the double build whatever the precision, as the one-slab finish kernel does --
-    // narrowing them first would make 1-shard and N-shard FP32 runs differ for nothing)
-    switch (args->variant) {
+  } else if (fp32) {
+    switch (v) {
       case 1: e = launch_step<1, float, 8>(*args, s); break;
       case 4: e = launch_step<4, float, 4>(*args, s); break;
       default: e = launch_step<2, float, 8>(*args, s); break;
     }
   } else {
-    switch (args->variant) {
+    switch (v) {
       case 1: e = launch_step<1, double, 8>(*args, s); break;
       case 2: e = launch_step<2, double, 4>(*args, s); break;
       case 3: e = launch_step<1, double, 4>(*args, s); break;
       case 4: e = launch_step<4, double, 2>(*args, s); break;
       case 5: e = launch_step<2, double, 8>(*args, s); break;
-      case 6: e = launch_small(*args, s); break;
-      case 7: e = launch_wave(*args, s); break;
-      default:
-        if (wave_size) { e = launch_wave(*args, s); break; }
-        // enough workgroups to give every SIMD >= 2 waves with 2 bodies per lane?
-        if (args->own_count >= 2 * 256 * 4 * 2 * 64) e = launch_step<2, double, 4>(*args, s);
-        else e = launch_step<1, double, 8>(*args, s);
-        break;
+      default: e = launch_small(*args, s); break;  // 6
     }
   }
   if (e != hipSuccess) {

@@ -72,12 +72,8 @@ namespace {
     }                                                                        \
   } while (0)
 
-int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
 
-bool is_sym_variant(int v) {
-  return v == NBODY_MI355X_VARIANT_SYM || v == NBODY_MI355X_VARIANT_SYM1 || v == NBODY_MI355X_VARIANT_SYM2 ||
-         v == NBODY_MI355X_VARIANT_SYM4 || v == NBODY_MI355X_VARIANT_SYM8;
-}
+using nbody_internal::is_sym_variant;
 
 // out[i] = sum over shards q = 0..P-1, in that order, of q's partial sums for this slab
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const double* __restrict__ own,
@@ -255,8 +251,7 @@ int multi_create(const nbody_mi355x_config& cfg, const int32_t* devices, int32_t
     m->sh[r].begin = base * r + std::min<int64_t>(r, rem);
   }
   const int64_t big = m->sh[0].count;
-  m->S = round_up(big, (big >= 65536 || cfg.variant == NBODY_MI355X_VARIANT_SYM8) ? 2048
-                       : (big >= 8192 ? 1024 : NBODY_MI355X_TILE));
+  m->S = slab_slots(big, cfg.variant);
   const int64_t S = m->S;
 
   // pair-symmetric kernels: when asked for, or by default for systems they pay off on
@@ -415,6 +410,23 @@ int multi_download(MultiSim* m, double* particles) {
           NBODY_MI355X_ERR_D2H, "copy state");
   }
   return sync_all(*m, NBODY_MI355X_ERR_D2H, "download");
+}
+
+int multi_kernel_in_use(MultiSim* m, int32_t* variant, int64_t* workspace_bytes) {
+  const Shard& s = m->sh[0];
+  *workspace_bytes = s.workspace ? s.workspace_bytes : 0;
+  nbody_mi355x_step_args a = base_args(*m, s, 0);
+  if (m->sym) {
+    a.acc_out = s.acc_all;
+    a.variant = m->sym_variant;
+    a.workspace = s.workspace;
+    a.workspace_bytes = s.workspace_bytes;
+  } else {
+    a.j0_begin = 0;
+    a.j0_end = static_cast<int64_t>(m->P) * m->S;
+    a.variant = is_sym_variant(m->cfg.variant) ? 0 : m->cfg.variant;
+  }
+  return nbody_mi355x_step_variant(&a, variant);
 }
 
 int multi_energy(MultiSim* m, double* ke, double* pe) {

@@ -55,7 +55,6 @@ namespace {
     }                                                                        \
   } while (0)
 
-int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
 
 // Small systems are launch-bound (a small step of N = 500 is a few microseconds of GPU
 // work): the substep loop of a big step is replayed from a hipGraph of kGraphSteps steps
@@ -145,10 +144,7 @@ extern "C" int nbody_mi355x_create(const nbody_mi355x_config* cfg, nbody_mi355x_
   s->cfg = *cfg;
   if (s->cfg.G == 0.0) s->cfg.G = NBODY_MI355X_G_REFERENCE;
   s->n = cfg->num_particles;
-  // large systems: slots in whole 1024- or 2048-body blocks so that the pair-symmetric
-  // kernels apply with their largest block (the padding is massless bodies, <= 3 % more)
-  s->slots = round_up(s->n, (s->n >= 65536 || cfg->variant == NBODY_MI355X_VARIANT_SYM8) ? 2048
-                            : (s->n >= 8192 ? 1024 : NBODY_MI355X_TILE));
+  s->slots = nbody_internal::slab_slots(s->n, cfg->variant);
   const size_t slab = sizeof(double) * 3 * static_cast<size_t>(s->slots);
   const int64_t eblocks = s->slots / NBODY_MI355X_TILE;
   bool ok = hipMalloc(&s->pos[0], slab) == hipSuccess && hipMalloc(&s->pos[1], slab) == hipSuccess &&
@@ -176,8 +172,9 @@ extern "C" int nbody_mi355x_create(const nbody_mi355x_config* cfg, nbody_mi355x_
     probe.precision = cfg->precision;
     int64_t need = 0;
     size_t free_b = 0, total_b = 0;
-    const bool wanted = cfg->variant == 0 || (cfg->variant >= NBODY_MI355X_VARIANT_SYM &&
-                                              cfg->variant <= NBODY_MI355X_VARIANT_SYM8);
+    // (small systems run the wave-per-body kernels by default: no workspace to hold)
+    const bool wanted = (cfg->variant == 0 && s->n > NBODY_MI355X_WAVE_MAX_BODIES) ||
+                        nbody_internal::is_sym_variant(cfg->variant);
     if (wanted && nbody_mi355x_step_workspace_bytes(&probe, &need) == NBODY_MI355X_OK && need > 0 &&
         hipMemGetInfo(&free_b, &total_b) == hipSuccess && static_cast<size_t>(need) < free_b / 2 &&
         hipMalloc(&s->workspace, static_cast<size_t>(need)) == hipSuccess) {
@@ -286,21 +283,8 @@ extern "C" int nbody_mi355x_host_free(void* p) {
   return NBODY_MI355X_OK;
 }
 
-extern "C" int nbody_mi355x_run_async(nbody_mi355x_sim* s, int64_t substeps, void* snapshot_out) {
-  if (!s || substeps <= 0) { set_error("run: bad arguments"); return NBODY_MI355X_ERR_INVALID; }
-  if (s->pending) { set_error("run: the previous run_async has not been waited for"); return NBODY_MI355X_ERR_INVALID; }
-  if (s->multi) {
-    const size_t n9 = 9 * static_cast<size_t>(s->n);
-    double* out = static_cast<double*>(snapshot_out);
-    if (snapshot_out && s->cfg.host_is_float) { s->host_tmp.resize(n9); out = s->host_tmp.data(); }
-    const int mrc = nbody_internal::multi_enqueue(s->multi, substeps, out);
-    // (on an error part of the step may be enqueued: wait() drains it)
-    s->pending = true;
-    s->pending_out = mrc == NBODY_MI355X_OK ? snapshot_out : nullptr;
-    if (mrc != NBODY_MI355X_OK) { (void)nbody_internal::multi_wait(s->multi, &s->last_run_seconds); s->pending = false; }
-    return mrc;
-  }
-  HIP_TRY(hipSetDevice(s->cfg.device), NBODY_MI355X_ERR_NO_DEVICE, "hipSetDevice");
+// a whole small step of the (one-device) handle, buffers left to the caller
+static nbody_mi355x_step_args step_args_of(const nbody_mi355x_sim* s) {
   nbody_mi355x_step_args a;
   memset(&a, 0, sizeof a);
   a.mass = s->mass;
@@ -319,12 +303,46 @@ extern "C" int nbody_mi355x_run_async(nbody_mi355x_sim* s, int64_t substeps, voi
   a.integrator = s->cfg.integrator;
   a.workspace = s->workspace;
   a.workspace_bytes = s->workspace_bytes;
+  return a;
+}
+
+static bool takes_tiny_path(const nbody_mi355x_sim* s) {
+  return s->n <= nbody_internal::kTinyMaxBodies &&
+         (s->cfg.variant == 0 || s->cfg.variant == NBODY_MI355X_VARIANT_TINY);
+}
+
+extern "C" int nbody_mi355x_kernel_in_use(nbody_mi355x_sim* s, int32_t* variant, int64_t* workspace_bytes) {
+  if (!s || !variant || !workspace_bytes) { set_error("kernel_in_use: null argument"); return NBODY_MI355X_ERR_INVALID; }
+  if (s->multi) return nbody_internal::multi_kernel_in_use(s->multi, variant, workspace_bytes);
+  *workspace_bytes = s->workspace ? s->workspace_bytes : 0;
+  if (takes_tiny_path(s)) { *variant = NBODY_MI355X_VARIANT_TINY; return NBODY_MI355X_OK; }
+  nbody_mi355x_step_args a = step_args_of(s);
+  a.pos_cur = s->pos[0];
+  a.pos_next = s->pos[1];
+  return nbody_mi355x_step_variant(&a, variant);
+}
+
+extern "C" int nbody_mi355x_run_async(nbody_mi355x_sim* s, int64_t substeps, void* snapshot_out) {
+  if (!s || substeps <= 0) { set_error("run: bad arguments"); return NBODY_MI355X_ERR_INVALID; }
+  if (s->pending) { set_error("run: the previous run_async has not been waited for"); return NBODY_MI355X_ERR_INVALID; }
+  if (s->multi) {
+    const size_t n9 = 9 * static_cast<size_t>(s->n);
+    double* out = static_cast<double*>(snapshot_out);
+    if (snapshot_out && s->cfg.host_is_float) { s->host_tmp.resize(n9); out = s->host_tmp.data(); }
+    const int mrc = nbody_internal::multi_enqueue(s->multi, substeps, out);
+    // (on an error part of the step may be enqueued: wait() drains it)
+    s->pending = true;
+    s->pending_out = mrc == NBODY_MI355X_OK ? snapshot_out : nullptr;
+    if (mrc != NBODY_MI355X_OK) { (void)nbody_internal::multi_wait(s->multi, &s->last_run_seconds); s->pending = false; }
+    return mrc;
+  }
+  HIP_TRY(hipSetDevice(s->cfg.device), NBODY_MI355X_ERR_NO_DEVICE, "hipSetDevice");
+  nbody_mi355x_step_args a = step_args_of(s);
   HIP_TRY(hipEventRecord(s->ev0, s->stream), NBODY_MI355X_ERR_LAUNCH, "event record");
   int64_t k = 0;
   // at most 64 bodies: the whole big step is ONE launch of one wave (tiny_run), in place on
   // pos[cur] -- the reference's two- and eight-body scenes take 324 000 small steps per big step
-  if (s->n <= nbody_internal::kTinyMaxBodies &&
-      (s->cfg.variant == 0 || s->cfg.variant == NBODY_MI355X_VARIANT_TINY)) {
+  if (takes_tiny_path(s)) {
     a.pos_cur = s->pos[s->cur];
     a.pos_next = nullptr;
     a.snapshot = snapshot_out ? s->aos : nullptr;

@@ -48,101 +48,14 @@
 #include <cstdlib>
 #include <mutex>
 
-#include "nbody_device.hpp"
 #include "nbody_internal.h"
+#include "nbody_sym_device.hpp"
 
 using namespace nbody_device;
+using namespace nbody_sym;
 using nbody_internal::set_error;
 
 namespace {
-
-struct SymArgs {
-  const double* pos;   // all slabs, slab layout
-  const double* mass;  // all slabs, flat
-  double* R;           // [nR][3][S]  i-side sums of the own rows, per distance chunk
-  double* C;           // [Db][3][S]  j-side sums of tile (I, I+d) at row d - c_base, indexed by
-                       //             OWN row I - row0; Db = distances per batch
-  int64_t S;           // slots per slab
-  int nbs;             // blocks per slab = S / B
-  int nb;              // blocks in all = num_shards * nbs
-  int row0;            // first own block row = own_shard * nbs
-  int D;               // largest distance = nb / 2
-  int d_lo, d_hi;      // distances this launch covers, inclusive
-  int dsplit;          // chunks [d_lo, d_hi] is cut into (grid.y)
-  int jsplit;          // parts a tile's j groups are cut into (grid.z): 1, 2, 4 or 8, <= IPT
-  int jlocal;          // the same for the launch of phase 1 (diagonal tiles only); host side only
-  int r_base;          // R chunk of this launch's chunk 0
-  int r_first;         // first R chunk the finishing kernels add (0 = include the local phase's)
-  int nR;              // one past the last R chunk they add
-  int c_base;          // distance stored in row 0 of C for this batch
-  int no_eq;           // 1: never take the equal-mass forms of the tile loop (tests)
-  double eps2;
-};
-
-// a pair of coordinates as staged in LDS: {x,y} and {z,m}, in the arithmetic type
-template <typename T>
-struct alignas(2 * sizeof(T)) P2 {
-  T a, b;
-};
-
-__device__ __forceinline__ double rotate_from_next_lane(double v) {
-  // lane l receives lane (l+1) mod 64's value: DPP wave_rol:1 on both halves
-  int lo = __double2loint(v), hi = __double2hiint(v);
-  // (every lane is written, so the "old" operand is never used: pass the source itself
-  // rather than a constant that would cost a v_mov)
-  lo = __builtin_amdgcn_update_dpp(lo, lo, 0x134, 0xf, 0xf, false);
-  hi = __builtin_amdgcn_update_dpp(hi, hi, 0x134, 0xf, 0xf, false);
-  return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ float rotate_from_next_lane(float v) {
-  int b = __float_as_int(v);
-  b = __builtin_amdgcn_update_dpp(b, b, 0x134, 0xf, 0xf, false);
-  return __int_as_float(b);
-}
-
-__device__ __forceinline__ double fma_t(double a, double b, double c) { return __builtin_fma(a, b, c); }
-__device__ __forceinline__ float fma_t(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
-
-// The two weights of one pair from its separation: si = m_j r^-3 (applied to body i) and
-// sj = m_i r^-3 (applied to body j; only computed when WANT_J).
-// double: rsq seed + folded series, r^2 chain seeded with 2^-600 or eps2 (nbody_device.hpp).
-// float (the FP32 variant): v_rsq_f32 is good to an ulp; r^2 == 0 is an explicit select
-// because 2^-600 does not exist in float; and the mass is multiplied in BEFORE the cube is
-// completed, (m y0) (y0 y0), so that r^-3 alone never underflows (r = 1e13 m: 1e-39).
-__device__ __forceinline__ double pair_r3(double dx, double dy, double dz, double eps2, double c15, double c1875) {
-  const double r2 = __builtin_fma(dz, dz, __builtin_fma(dy, dy, __builtin_fma(dx, dx, eps2)));
-  const double y0 = __builtin_amdgcn_rsq(r2);
-  const double u = y0 * y0;
-  const double e = __builtin_fma(-r2, u, 1.0);
-  const double w0 = y0 * u;
-  const double p = __builtin_fma(e, c1875, c15);
-  const double we = w0 * e;
-  return __builtin_fma(we, p, w0);  // r^-3
-}
-__device__ __forceinline__ float pair_r3(float, float, float, float, float, float) { return 0.0f; }  // (double only)
-template <bool WANT_J>
-__device__ __forceinline__ void pair_weights(double dx, double dy, double dz, double mj, double mi, double eps2,
-                                             double c15, double c1875, double* si, double* sj) {
-  const double s0 = pair_r3(dx, dy, dz, eps2, c15, c1875);
-  *si = s0 * mj;
-  if (WANT_J) *sj = s0 * mi;
-}
-template <bool WANT_J>
-__device__ __forceinline__ void pair_weights(float dx, float dy, float dz, float mj, float mi, float eps2,
-                                             float, float, float* si, float* sj) {
-  const float r2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, __builtin_fmaf(dx, dx, eps2)));
-  const float y = __builtin_amdgcn_rsqf(r2);
-  const float y0 = (r2 > 0.0f) ? y : 0.0f;
-  const float y2 = y0 * y0;
-  *si = (mj * y0) * y2;
-  if (WANT_J) *sj = (mi * y0) * y2;
-}
-
-// LDS layout of a staged tile: each group of 64 j bodies takes kGrp = 72 entries, of which
-// entries 64..71 repeat 0..7.  A lane that walks its group from entry r (0..63) can then
-// read 8 consecutive steps at immediate offsets without wrapping, so the inner loop has no
-// address arithmetic (2 integer instructions per 8 steps instead of 7 per 2).
-constexpr int kGrp = 72;
 
 // j groups of a tile that are staged in LDS at a time: 16 groups = 1024 bodies = 63 KB in
 // double, two workgroups per CU.  Blocks of up to 1024 bodies (IPT <= 4) are staged whole;
@@ -151,29 +64,9 @@ constexpr int kStageGroups = 16;
 template <int IPT>
 constexpr int staged_groups() { return 4 * IPT < kStageGroups ? 4 * IPT : kStageGroups; }
 
-// The workgroup's j groups of the staged tile against this wave's 64*IPT bodies.  SYM = false is
-// the diagonal tile (a block against itself): i side only, no barriers needed.
-// The j-side sums travel with their body through the lanes: one DPP wave rotation per step,
-// 6 v_mov_b32_dpp (3.3 cycles each) per IPT pairs.  (Sending each step's sums to the body's
-// LDS entry with a return-less ds_add_f64 instead was tried: it removes the moves, but an
-// LDS atomic with 64-bit data holds up the SIMD's VALU issue for ~12 cycles, 3 of them cost
-// more than the 6 moves -- tools/ubench_lds.hip)
-// MODE selects how the masses enter (workgroup-uniform, chosen per LDS fill):
-//   kGeneral   si = m_j r^-3, sj = m_i r^-3: 20 FP64 operations per pair.
-//   kDeferred  (double) every body of the row AND of the staged groups has the one mass
-//              m_ref: both sides take the bare r^-3 and the mass is multiplied in once per
-//              sum instead of once per pair -- the j sums when a wave adds them to LDS, the
-//              i sums (which stay in units of 1/m_ref for the whole row) when the row is
-//              stored: 18 operations per pair.  The benchmark scenes (Plummer sphere,
-//              uniform cube) are equal-mass systems, and so are all but one row of a ring.
-//   kRowUnit   (double) the row has one mass but the staged bodies do not (a padded block,
-//              the ring's planet): the i sums are in units of 1/m_ref, so the i-side weight
-//              is (m_j r^-3) / m_ref; j side as kGeneral.  Rare; 21 operations.
-//   kSameMass  (float) as kDeferred's condition, but the mass stays in the product (r^-3
-//              alone can leave float's range) and one product serves both sides: 19.
-// kDeferred / kRowUnit round once more per sum than kGeneral (the final product with m_ref):
-// results agree to an ulp or two of each sum, not bit for bit.
-enum { kGeneral = 0, kDeferred = 1, kRowUnit = 2, kSameMass = 3 };
+// The workgroup's j groups of the staged tile against this wave's 64*IPT bodies (group_steps,
+// nbody_sym_device.hpp).  SYM = false is the diagonal tile (a block against itself): i side
+// only, no barriers needed.  MODE: how the masses enter, chosen per LDS fill.
 template <int IPT, bool SYM, int MODE, typename T>
 __device__ __forceinline__ void tile_phases(const P2<T>* xy, const P2<T>* zm, T (*fJ)[kGrp * staged_groups<IPT>()],
                                             int lane, int w, int ng, const T (&xi)[IPT], const T (&yi)[IPT],
@@ -183,59 +76,10 @@ __device__ __forceinline__ void tile_phases(const P2<T>* xy, const P2<T>* zm, T 
   for (int ph = 0; ph < ng; ph++) {
     const int grp = (ph + (ng >> 2) * w) % ng;  // the 4 waves sit on 4 different groups
     const int gb = grp * kGrp;
-    T fx = 0, fy = 0, fz = 0;
-    int rot = lane;  // at step t the lane meets body (lane + t) mod 64 of the group
-    // the body of the NEXT step is read while this step's pairs are evaluated: two register
-    // sets used alternately (8 steps per trip: the roles are the same at every trip's start)
-    P2<T> bxy[2], bzm[2];
-    bxy[0] = xy[gb + rot];
-    bzm[0] = zm[gb + rot];
-    for (int t8 = 0; t8 < 8; t8++) {
-      const int rot_next = (rot + 8) & 63;
-      const P2<T>* pxy = xy + gb + rot;
-      const P2<T>* pzm = zm + gb + rot;
-#pragma unroll
-      for (int u = 0; u < 8; u++) {
-        // (after the last step this reads the group's first body again: a valid address)
-        bxy[(u + 1) & 1] = u < 7 ? pxy[u + 1] : xy[gb + rot_next];
-        bzm[(u + 1) & 1] = u < 7 ? pzm[u + 1] : zm[gb + rot_next];
-        const P2<T> jxy = bxy[u & 1];
-        const P2<T> jzm = bzm[u & 1];
-#pragma unroll
-        for (int k = 0; k < IPT; k++) {
-          const T dx = jxy.a - xi[k];
-          const T dy = jxy.b - yi[k];
-          const T dz = jzm.a - zi[k];
-          T si, sj = 0;
-          if constexpr (MODE == kDeferred) {
-            si = sj = pair_r3(dx, dy, dz, eps2, c15, c1875);
-          } else if constexpr (MODE == kRowUnit) {
-            pair_weights<SYM>(dx, dy, dz, jzm.b, mi[k], eps2, c15, c1875, &si, &sj);
-            si *= inv_m_ref;
-          } else if constexpr (MODE == kSameMass) {
-            pair_weights<false>(dx, dy, dz, jzm.b, mi[k], eps2, c15, c1875, &si, &sj);
-            sj = si;
-          } else {
-            pair_weights<SYM>(dx, dy, dz, jzm.b, mi[k], eps2, c15, c1875, &si, &sj);
-          }
-          ax[k] = fma_t(si, dx, ax[k]);
-          ay[k] = fma_t(si, dy, ay[k]);
-          az[k] = fma_t(si, dz, az[k]);
-          if (SYM) {
-            fx = fma_t(-sj, dx, fx);
-            fy = fma_t(-sj, dy, fy);
-            fz = fma_t(-sj, dz, fz);
-          }
-        }
-        if (SYM) {  // the sums follow their body to the lane that meets it next
-          fx = rotate_from_next_lane(fx);
-          fy = rotate_from_next_lane(fy);
-          fz = rotate_from_next_lane(fz);
-        }
-      }
-      rot = rot_next;
-    }
-    if (SYM) {  // 64 rotations later the sums are home: lane l holds body l of the group
+    T fx, fy, fz;
+    group_steps<IPT, SYM, MODE, T>(xy, zm, gb, lane, xi, yi, zi, mi, ax, ay, az, eps2, c15, c1875, inv_m_ref, &fx, &fy,
+                                   &fz);
+    if (SYM) {  // the sums are home: lane l holds body l of the group
       if constexpr (MODE == kDeferred) {
         fx *= m_ref;
         fy *= m_ref;
@@ -247,65 +91,6 @@ __device__ __forceinline__ void tile_phases(const P2<T>* xy, const P2<T>* zm, T 
       __syncthreads();  // next phase another wave adds to this group
     }
   }
-}
-
-// first slot of block J in the slab layout: coordinates via *x (y at +S, z at +2S), mass via *m
-template <int B>
-__device__ __forceinline__ void block_base(const SymArgs& a, int J, const double** x, const double** m) {
-  const int slab = J / a.nbs;
-  const int64_t off = static_cast<int64_t>(J - slab * a.nbs) * B;
-  *x = a.pos + static_cast<int64_t>(slab) * 3 * a.S + off;
-  *m = a.mass + static_cast<int64_t>(slab) * a.S + off;
-}
-
-// FP32 variant: where a row's coordinates are measured from.  A float holds a coordinate to
-// 6e-8 of its MAGNITUDE, so narrowing absolute positions makes close pairs of a system that
-// sits far from the origin cancel (a cluster of size 1 at distance 2e3: ulp 1.2e-4).  The
-// reference's float instantiation differences full-precision inputs (particle_simulation.h:
-// 257-270); here the row's bodies and every j body staged against them are taken relative
-// to one point, in double, and only the (small) relative coordinate is narrowed.  The point
-// is the centroid of the row's real bodies -- for bodies in no spatial order that is the
-// system's centre, for sorted ones the block's own neighbourhood.  Padding slots (mass 0 at
-// the origin) are not counted; a centroid that is not finite (NaN / inf input) falls back to
-// 0, i.e. absolute coordinates, so that garbage spreads exactly as before.  Every workgroup
-// of a row adds in the same fixed order: the same origin, bit for bit, run to run.
-__device__ __forceinline__ double uniform(double v) {  // a wave-uniform value into SGPRs
-  return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)),
-                          __builtin_amdgcn_readfirstlane(__double2loint(v)));
-}
-template <int IPT>
-__device__ __forceinline__ void row_origin(const double* px, const double* pm, int64_t S, int tid, double* ox,
-                                           double* oy, double* oz) {
-  __shared__ double cen[4][4];
-  double sx = 0.0, sy = 0.0, sz = 0.0, cnt = 0.0;
-#pragma unroll
-  for (int k = 0; k < IPT; k++) {
-    const int idx = k * 256 + tid;
-    const double x = px[idx], y = px[S + idx], z = px[2 * S + idx];
-    const bool padding = pm[idx] == 0.0 && x == 0.0 && y == 0.0 && z == 0.0;
-    sx += x; sy += y; sz += z;
-    cnt += padding ? 0.0 : 1.0;
-  }
-  for (int o = 32; o > 0; o >>= 1) {
-    sx += __shfl_down(sx, o, 64);
-    sy += __shfl_down(sy, o, 64);
-    sz += __shfl_down(sz, o, 64);
-    cnt += __shfl_down(cnt, o, 64);
-  }
-  if ((tid & 63) == 0) {
-    cen[tid >> 6][0] = sx; cen[tid >> 6][1] = sy; cen[tid >> 6][2] = sz; cen[tid >> 6][3] = cnt;
-  }
-  __syncthreads();
-  const double n = cen[0][3] + cen[1][3] + cen[2][3] + cen[3][3];
-  const double cx = (cen[0][0] + cen[1][0] + cen[2][0] + cen[3][0]) / n;
-  const double cy = (cen[0][1] + cen[1][1] + cen[2][1] + cen[3][1]) / n;
-  const double cz = (cen[0][2] + cen[1][2] + cen[2][2] + cen[3][2]) / n;
-  const bool ok = n > 0.0 && (cx - cx == 0.0) && (cy - cy == 0.0) && (cz - cz == 0.0);
-  // workgroup-uniform: kept in scalar registers (the float IPT = 4 build sits at the VGPR
-  // count that still allows two waves per SIMD; six more VGPRs halve its occupancy)
-  *ox = uniform(ok ? cx : 0.0);
-  *oy = uniform(ok ? cy : 0.0);
-  *oz = uniform(ok ? cz : 0.0);
 }
 
 template <int IPT, typename T>
@@ -462,12 +247,12 @@ __global__ __launch_bounds__(256) void sym_tiles_kernel(const SymArgs a) {
 // flight on these memory-bound kernels (a slot has up to ~300 partials of 24 bytes), still one
 // fixed order of additions.
 constexpr int kParts = 4;
-template <int B>
 __device__ __forceinline__ void sum_partials(const SymArgs& sa, int slab, int64_t off, bool own_slab, int part,
                                              double* ax, double* ay, double* az) {
   const int64_t S = sa.S;
-  const int J = slab * sa.nbs + static_cast<int>(off / B);
-  const int jl = static_cast<int>(off % B);
+  const int B = 1 << sa.bshift;  // block size of the kernel family that produced the partials
+  const int J = slab * sa.nbs + static_cast<int>(off >> sa.bshift);
+  const int jl = static_cast<int>(off & (B - 1));
   double x = 0.0, y = 0.0, z = 0.0;
   // (unrolled so that several partials' loads are in flight; the order of the adds is unchanged)
   if (own_slab) {
@@ -486,7 +271,7 @@ __device__ __forceinline__ void sum_partials(const SymArgs& sa, int slab, int64_
     int d = J - I;
     if (d < 0) d += sa.nb;
     if (d < d_min || d > sa.d_hi || (2 * d == sa.nb && I >= sa.nb / 2)) continue;
-    const double* Cd = sa.C + static_cast<int64_t>(d - sa.c_base) * 3 * S + static_cast<int64_t>(il) * B + jl;
+    const double* Cd = sa.C + static_cast<int64_t>(d - sa.c_base) * 3 * S + (static_cast<int64_t>(il) << sa.bshift) + jl;
     x += Cd[0];
     y += Cd[S];
     z += Cd[2 * S];
@@ -516,13 +301,12 @@ __device__ __forceinline__ void combine_parts(double* ax, double* ay, double* az
 }
 
 // one slab, one batch: the partial sums are the complete sums -> integrate directly
-template <int IPT>
 __global__ __launch_bounds__(256) void sym_finish_kernel(const SymArgs sa, const nbody_mi355x_step_args a) {
   const int64_t g = static_cast<int64_t>(blockIdx.x) * 64 + threadIdx.x;
   const bool real = g < a.own_count;
   const int64_t S = sa.S;
   double ax = 0.0, ay = 0.0, az = 0.0;
-  if (real) sum_partials<256 * IPT>(sa, 0, g, true, threadIdx.y, &ax, &ay, &az);
+  if (real) sum_partials(sa, 0, g, true, threadIdx.y, &ax, &ay, &az);
   combine_parts(&ax, &ay, &az);
   if (real && threadIdx.y == 0)
     integrate_and_store(a, g, a.pos_cur[g], a.pos_cur[S + g], a.pos_cur[2 * S + g], ax, ay, az);
@@ -530,7 +314,6 @@ __global__ __launch_bounds__(256) void sym_finish_kernel(const SymArgs sa, const
 
 // several slabs (ranks) and/or several batches: this rank's partial sums of this batch for
 // EVERY slot into out[num_shards][3][S] (first batch: stored; later batches: added).
-template <int IPT>
 __global__ __launch_bounds__(256) void sym_gather_kernel(const SymArgs sa, int own_shard, int num_shards,
                                                          bool first, double* __restrict__ out) {
   const int64_t S = sa.S;
@@ -539,7 +322,7 @@ __global__ __launch_bounds__(256) void sym_gather_kernel(const SymArgs sa, int o
   const int slab = real ? static_cast<int>(g / S) : 0;
   const int64_t off = real ? g - static_cast<int64_t>(slab) * S : 0;
   double ax = 0.0, ay = 0.0, az = 0.0;
-  if (real) sum_partials<256 * IPT>(sa, slab, off, slab == own_shard, threadIdx.y, &ax, &ay, &az);
+  if (real) sum_partials(sa, slab, off, slab == own_shard, threadIdx.y, &ax, &ay, &az);
   combine_parts(&ax, &ay, &az);
   if (!real || threadIdx.y != 0) return;
   double* o = out + static_cast<int64_t>(slab) * 3 * S + off;
@@ -565,26 +348,51 @@ __global__ __launch_bounds__(256) void sym_integrate_kernel(const double* __rest
 }
 
 struct Plan {
+  bool wave;  // wave tiles (nbody_symw.hip): blocks of 64 * ipt slots; else workgroup tiles: 256 * ipt
   int ipt, nbs, nb, D, dsplit, jsplit, jlocal;
+  int per;      // wave tiles: entries of a row's (tile, group) list per workgroup
+  int rchunks;  // R chunks the main launch writes per row (dsplit * jsplit / the list's chunks)
+  int64_t block;      // slots per block
   int64_t bytes;      // preferred workspace: every distance in one batch, capped (kBatchCap)
   int64_t row_bytes;  // 3 * S doubles: one R chunk / one distance of C / the batch accumulator
 };
 
 // Above this the distances are processed in batches that reuse the C rows (the workspace
-// of one batch would otherwise grow as N^2 / block: 206 GB at N = 4M on one GPU).
-constexpr int64_t kBatchCap = int64_t{16} << 30;
+// of one batch would otherwise grow as N^2 / block: 7.3 GB at N = 1M, 206 GB at N = 4M on one
+// GPU).  Every batch is a launch of its own with a ramp and a tail; measured at N = 1M
+// (ms per step by cap): 1 GiB 362.6, 2 GiB 352.7, 4 GiB 351.5, unbatched (7.3 GB) 351.1.
+// Larger systems need room for a few distances per chunk of a row to keep the launches long:
+// the cap is never below four times the plan's minimum.
+constexpr int64_t kBatchCap = int64_t{4} << 30;
 
-// rows of the workspace that are not C: R chunks (jlocal of phase 1 + ds * js) and, on one
-// slab, the accumulator that batches add into
+// rows of the workspace that are not C: R chunks (jlocal of phase 1 + the main launch's) and,
+// on one slab, the accumulator that batches add into
 int64_t fixed_rows(const Plan& p, int num_shards) {
-  return p.jlocal + static_cast<int64_t>(p.dsplit) * p.jsplit + (num_shards == 1 ? 1 : 0);
+  return p.jlocal + static_cast<int64_t>(p.rchunks) + (num_shards == 1 ? 1 : 0);
 }
 
-// One candidate block size: fills *p and returns its modelled time (arbitrary units), or a
-// negative value if it does not apply.
+int env_int(const char* name) {  // tuning experiments only
+  const char* env = getenv(name);
+  return env ? atoi(env) : 0;
+}
+
+void plan_bytes(const nbody_mi355x_step_args& a, Plan* p) {
+  p->row_bytes = static_cast<int64_t>(sizeof(double)) * 3 * a.shard_slots;
+  const int64_t full = p->row_bytes * (fixed_rows(*p, a.num_shards) + p->D);
+  const int64_t least = p->row_bytes * (fixed_rows(*p, a.num_shards) + 1);
+  int64_t cap = kBatchCap > 4 * least ? kBatchCap : 4 * least;
+  if (const int mb = env_int("NBODY_MI355X_SYM_WS_CAP_MB"); mb > 0) cap = static_cast<int64_t>(mb) << 20;
+  p->bytes = full <= cap ? full : (least > cap ? least : cap);
+}
+
+// One candidate block size of the workgroup-tile kernels: fills *p and returns its modelled
+// time (arbitrary units), or a negative value if it does not apply.
 double plan_for(const nbody_mi355x_step_args& a, int ipt, Plan* p) {
   const int64_t B = 256 * ipt;
   if (a.num_shards < 1 || a.shard_slots <= 0 || a.shard_slots % B != 0) return -1.0;
+  p->wave = false;
+  p->per = 0;
+  p->block = B;
   p->ipt = ipt;
   p->nbs = static_cast<int>(a.shard_slots / B);
   const int64_t nb = static_cast<int64_t>(p->nbs) * a.num_shards;
@@ -604,20 +412,15 @@ double plan_for(const nbody_mi355x_step_args& a, int ipt, Plan* p) {
   const int nd = p->D + 1;
   const int ds_cap = ipt == 8 ? 32 : 16;  // (measured: smaller blocks gain nothing beyond 16)
   int ds = nd < ds_cap ? nd : ds_cap;
-  if (const char* env = getenv("NBODY_MI355X_SYM_DSPLIT")) {  // tuning experiments only
-    const int v = atoi(env);
-    if (v > 0) ds = v;
-  }
+  if (const int v = env_int("NBODY_MI355X_SYM_DSPLIT"); v > 0) ds = v;
   if (ds > p->D) ds = p->D;
   if (ds < 1) ds = 1;
   p->dsplit = ds;
   int js = 1;
   while (js < ipt && static_cast<int64_t>(p->nbs) * nd * js < 64 * 256) js *= 2;
-  if (const char* env = getenv("NBODY_MI355X_SYM_JSPLIT")) {  // tuning experiments only
-    const int v = atoi(env);
-    if ((v == 1 || v == 2 || v == 4 || v == 8) && v <= ipt) js = v;
-  }
+  if (const int v = env_int("NBODY_MI355X_SYM_JSPLIT"); (v == 1 || v == 2 || v == 4 || v == 8) && v <= ipt) js = v;
   p->jsplit = js;
+  p->rchunks = ds * js;
   // phase 1 (multi-rank runs: the diagonal tiles, while the all-gather is in flight) has one
   // tile per own row: with few rows per rank the tiles are split so that the launch still
   // puts two workgroups on every CU (8 ranks at N = 1M: 64 rows -> 512 workgroups of 1/8 tile;
@@ -627,25 +430,127 @@ double plan_for(const nbody_mi355x_step_args& a, int ipt, Plan* p) {
   p->jlocal = a.num_shards > 1 ? jl : 1;
   const double tile = static_cast<double>(B) * static_cast<double>(B) * pair_cost;
   const double best = static_cast<double>(p->nbs) * nd * tile / 256.0 + tile / js * per_cu;
-  p->row_bytes = static_cast<int64_t>(sizeof(double)) * 3 * a.shard_slots;
-  const int64_t full = p->row_bytes * (fixed_rows(*p, a.num_shards) + p->D);
-  const int64_t least = p->row_bytes * (fixed_rows(*p, a.num_shards) + 1);
-  p->bytes = full <= kBatchCap ? full : (least > kBatchCap ? least : kBatchCap);
+  plan_bytes(a, p);
   return best;
 }
 
-// The plan is a pure function of (shard_slots, num_shards, variant): the workspace query
-// and the step agree on it.
+// The wave-tile kernels (nbody_symw.hip) with blocks of 64 * ipt slots.  A row's work is the
+// list of its (tile, group) entries -- (D+1) tiles of ipt groups of 64 j bodies -- cut into
+// chunks of `per` entries, one workgroup each, whose 4 waves (all holding the row's bodies)
+// take every fourth entry.  `per` (a multiple of 4 up to 64) is chosen by a small model of
+// the launch, evaluated for every candidate; *model_us receives the winner's estimate, which
+// make_plan compares across block sizes.
+//   * a workgroup of e entries keeps each SIMD of its CU busy for ceil(e / 4) entry times; the
+//     hardware hands workgroups out in blockIdx order (x = rows fastest, so all full chunks
+//     first, the rows' remainder chunks last) to whichever CU has room: nbs * (entries / per)
+//     equal items over 256 CUs take ceil(items / 256) item times, and the remainder chunks
+//     fill the gaps that leaves, or run after;
+//   * every chunk costs one R row (24 bytes per slot) to store and to add again, every
+//     distance one C row: ~9 microseconds per million slots each (measured: 65 536 bodies,
+//     512-body blocks, per = 4 / 8 / 16 / 32 / 64: 1498 / 1476 / 1455 / 1449 / 1450 us).
+// Entry times (64 rotation steps of ipt pairs, microseconds at the ~2.2 GHz the chip holds):
+// 3.4 / 5.7 / 10.8 / 20.7 for ipt = 1 / 2 / 4 / 8 -- the 6 DPP moves and 2 LDS reads of a step
+// are shared by ipt pairs.  Measured on MI355X against the model (us per step, best per):
+// 8192 bodies, 128-body blocks: 39.3; 16 384, 256: 108; 32 768, 512: 379; 65 536, 512: 1420.
+// Sizes that are not powers of two are where the model earns its keep: 12 288 bodies with a
+// fixed per = 16 are 288 full items on 256 CUs -- two rounds for 1.1 rounds' work (97 us).
+constexpr int64_t kWaveTileMaxSlots = 196608;  // wave tiles up to here, workgroup tiles beyond
+double plan_wave(const nbody_mi355x_step_args& a, int ipt, Plan* p) {
+  const int64_t B = 64 * ipt;
+  if (a.num_shards < 1 || a.shard_slots <= 0 || a.shard_slots % B != 0) return -1.0;
+  if (ipt == 8 && a.precision == NBODY_MI355X_FP32) return -1.0;  // (not instantiated for float)
+  p->wave = true;
+  p->block = B;
+  p->ipt = ipt;
+  p->nbs = static_cast<int>(a.shard_slots / B);
+  const int64_t nb = static_cast<int64_t>(p->nbs) * a.num_shards;
+  if (nb < 2 || nb > (1 << 24)) return -1.0;
+  p->nb = static_cast<int>(nb);
+  p->D = p->nb / 2;
+  const int64_t entries = static_cast<int64_t>(p->D + 1) * ipt;  // per row
+  const double t_entry = ipt == 1 ? 3.4 : (ipt == 2 ? 5.7 : (ipt == 4 ? 10.8 : 20.7));
+  const double t_row = 9e-6 * static_cast<double>(a.shard_slots);  // one R or C row, stored and read back
+  constexpr int64_t kCUs = 256;
+  int64_t best_per = 4;
+  double best = -1.0;
+  for (int64_t per = 4; per <= 64; per += 4) {
+    const int64_t full = entries / per, rem = entries % per;
+    const int64_t n_full = p->nbs * full, c_full = per / 4, c_rem = (rem + 3) / 4;
+    const int64_t rounds = (n_full + kCUs - 1) / kCUs, last = n_full % kCUs;
+    double t = static_cast<double>(rounds * c_full);
+    if (rem > 0) {
+      // remainder chunks: into the last round's idle CUs while it runs, the rest after it
+      const int64_t room = (last > 0 && c_rem > 0) ? (kCUs - last) * (c_full / c_rem) : 0;
+      const int64_t left = p->nbs > room ? p->nbs - room : 0;
+      t += static_cast<double>((left + kCUs - 1) / kCUs * c_rem);
+    }
+    const double work = static_cast<double>(p->nbs) * static_cast<double>((entries + 3) / 4) / kCUs;
+    if (t < work) t = work;
+    // a CU that holds a single workgroup at a time (one wave per SIMD) runs it at ~3/4 of the
+    // rate two or more reach between them (measured: 16 384 bodies, 256 workgroups of 8 entries
+    // 102 us, 512 of 4 entries 100 us for half the depth); and every workgroup costs ~2 us of
+    // its own (the row's bodies in, the four waves' sums through LDS, the R row out), hidden
+    // only in part by its CU's other workgroups
+    const int64_t wgs = n_full + (rem > 0 ? p->nbs : 0);
+    const double resident = static_cast<double>(wgs) / kCUs;
+    const double rate = resident >= 2.0 ? 1.0 : (resident <= 1.0 ? 0.75 : 0.75 + 0.25 * (resident - 1.0));
+    const double t_wg = 1.0 * static_cast<double>((wgs + kCUs - 1) / kCUs);
+    t = t * t_entry / rate + t_wg + static_cast<double>(full + (rem > 0 ? 1 : 0)) * t_row;
+    if (best < 0.0 || t < best) {
+      best = t;
+      best_per = per;
+    }
+  }
+  if (const int v = env_int("NBODY_MI355X_SYMW_PER"); v >= 4 && v % 4 == 0) best_per = v;
+  p->per = static_cast<int>(best_per);
+  p->rchunks = static_cast<int>((entries + best_per - 1) / best_per);
+  p->dsplit = p->jsplit = 1;
+  p->jlocal = (ipt + 3) / 4;  // phase 1: the ipt entries of the diagonal tile, 4 per workgroup
+  plan_bytes(a, p);
+  return best + static_cast<double>(p->D) * t_row;
+}
+
+// The plan is a pure function of (shard_slots, num_shards, variant, precision): the workspace
+// query and the step agree on it.
 bool make_plan(const nbody_mi355x_step_args& a, Plan* p) {
   if (a.variant == NBODY_MI355X_VARIANT_SYM1) return plan_for(a, 1, p) >= 0.0;
   if (a.variant == NBODY_MI355X_VARIANT_SYM2) return plan_for(a, 2, p) >= 0.0;
   if (a.variant == NBODY_MI355X_VARIANT_SYM4) return plan_for(a, 4, p) >= 0.0;
   if (a.variant == NBODY_MI355X_VARIANT_SYM8) return plan_for(a, 8, p) >= 0.0;
-  // automatic: the largest block that still leaves enough tiles per rank to keep 512
-  // resident workgroups busy to the end.  Bigger blocks cost fewer DPP moves per pair, but
+  if (a.variant == NBODY_MI355X_VARIANT_SYMW1) return plan_wave(a, 1, p) >= 0.0;
+  if (a.variant == NBODY_MI355X_VARIANT_SYMW2) return plan_wave(a, 2, p) >= 0.0;
+  if (a.variant == NBODY_MI355X_VARIANT_SYMW4) return plan_wave(a, 4, p) >= 0.0;
+  if (a.variant == NBODY_MI355X_VARIANT_SYMW8) return plan_wave(a, 8, p) >= 0.0;
+  // automatic.  Up to kWaveTileMaxSlots slots in all: wave tiles, whose work items are small
+  // enough to level the load of a short launch; block size by system size.  Measured on
+  // MI355X (Ginteractions/s, equal masses; workgroup tiles of the best block in brackets):
+  // 8192 bodies: 128-body blocks 1707, 256: 1657, 64: 1467 (1177); 16 384: 256: 2487, 512: 2297
+  // (1893); 32 768: 256: 2861, 512: 2830 (2578); 65 536: 512: 3025, 256: 2978 (2857); 131 072:
+  // 512: 3019 (2985); 262 144: 2938 (2936); 524 288: 2969 (3012); 1 048 576: 2971 (3040) --
+  // the j-side sums are stored after meeting 512 bodies instead of 2048, traffic that grows
+  // as N^2, so the large systems keep workgroup tiles.
+  {
+    const int64_t total = a.shard_slots * a.num_shards;
+    if (total <= kWaveTileMaxSlots) {
+      // the block size whose modelled launch is the shortest (64-body blocks: only where no
+      // larger one divides the slab)
+      double best = -1.0;
+      for (int ipt : {8, 4, 2, 1}) {
+        Plan c;
+        const double t = plan_wave(a, ipt, &c);
+        if (t < 0.0 || (ipt == 1 && best >= 0.0)) continue;
+        if (best < 0.0 || t < best) {
+          best = t;
+          *p = c;
+        }
+      }
+      if (best >= 0.0) return true;
+    }
+  }
+  // Beyond: workgroup tiles, the largest block that still leaves enough tiles per rank to keep
+  // 512 resident workgroups busy to the end.  Bigger blocks cost fewer DPP moves per pair, but
   // a launch of few big tiles is mostly ramp and tail.  Thresholds from sweeps on MI355X
-  // (Ginteractions/s, best block per size): 16 384 bodies: 256-body blocks 1665 (1024: 1326);
-  // 32 768: 512 2371 (2048: 2264); 65 536: 1024 2802 (2048: 2744); 131 072: 1024 2880
+  // (Ginteractions/s, best block per size): 65 536: 1024 2802 (2048: 2744); 131 072: 1024 2880
   // (2048: 2783); 262 144 and up: 2048.  The model value of plan_for only breaks ties.
   for (int ipt : {8, 4, 2, 1}) {
     Plan c;
@@ -664,14 +569,32 @@ bool make_plan(const nbody_mi355x_step_args& a, Plan* p) {
 }
 
 template <int IPT, typename T>
-hipError_t launch(SymArgs sa, const nbody_mi355x_step_args& a, hipStream_t stream, int batch, double* accum) {
+hipError_t launch_wg_tiles(const SymArgs& sa, dim3 grid, hipStream_t stream) {
+  hipLaunchKernelGGL((sym_tiles_kernel<IPT, T>), grid, dim3(256), 0, stream, sa);
+  return hipGetLastError();
+}
+
+// the tile kernel of the plan's family, block size and arithmetic
+hipError_t launch_tiles(const Plan& p, bool fp32, const SymArgs& sa, dim3 grid, hipStream_t stream) {
+  if (p.wave) return nbody_sym::launch_wave_tiles(p.ipt, fp32, sa, grid, stream);
+  if (fp32)
+    return p.ipt == 1 ? launch_wg_tiles<1, float>(sa, grid, stream)
+           : p.ipt == 2 ? launch_wg_tiles<2, float>(sa, grid, stream) : launch_wg_tiles<4, float>(sa, grid, stream);
+  return p.ipt == 1 ? launch_wg_tiles<1, double>(sa, grid, stream)
+         : p.ipt == 2 ? launch_wg_tiles<2, double>(sa, grid, stream)
+         : p.ipt == 4 ? launch_wg_tiles<4, double>(sa, grid, stream) : launch_wg_tiles<8, double>(sa, grid, stream);
+}
+
+hipError_t launch(const Plan& p, SymArgs sa, const nbody_mi355x_step_args& a, hipStream_t stream, int batch,
+                  double* accum) {
   hipError_t e = hipSuccess;
-  // phase 1 = what needs the own slab only (the diagonal tiles), kept in R[0];
+  const bool fp32 = a.precision == NBODY_MI355X_FP32;
+  // phase 1 = what needs the own slab only (the diagonal tiles), kept in R[0 .. jlocal);
   // phase 2 = the rest, then output; phase 0 = both
   if (a.phase == 1) {
     sa.d_lo = 0; sa.d_hi = 0; sa.dsplit = 1; sa.jsplit = sa.jlocal; sa.r_base = 0; sa.c_base = 1;
-    hipLaunchKernelGGL((sym_tiles_kernel<IPT, T>), dim3(sa.nbs, 1, sa.jlocal), dim3(256), 0, stream, sa);
-    return hipGetLastError();
+    sa.per = 4;
+    return launch_tiles(p, fp32, sa, p.wave ? dim3(sa.nbs, sa.jlocal, 1) : dim3(sa.nbs, 1, sa.jlocal), stream);
   }
   const int d_first = a.phase == 2 ? 1 : 0;
   sa.r_base = sa.jlocal;
@@ -685,16 +608,21 @@ hipError_t launch(SymArgs sa, const nbody_mi355x_step_args& a, hipStream_t strea
     sa.d_hi = hi;
     sa.c_base = lo > 1 ? lo : 1;
     sa.r_first = (first && a.phase == 2) ? 0 : sa.jlocal;  // the local phase's chunks join the first batch
-    hipLaunchKernelGGL((sym_tiles_kernel<IPT, T>), dim3(sa.nbs, sa.dsplit, sa.jsplit), dim3(256), 0, stream, sa);
-    e = hipGetLastError();
+    dim3 grid(sa.nbs, sa.dsplit, sa.jsplit);
+    if (p.wave) {  // this launch's part of every row's list, `per` entries per workgroup
+      const int chunks = ((hi - lo + 1) * p.ipt + p.per - 1) / p.per;
+      grid = dim3(sa.nbs, chunks, 1);
+      sa.nR = sa.r_base + chunks;
+    }
+    e = launch_tiles(p, fp32, sa, grid, stream);
     if (e != hipSuccess) return e;
     if (only && a.acc_out == nullptr) {
-      hipLaunchKernelGGL((sym_finish_kernel<IPT>), dim3(static_cast<unsigned>((a.own_count + 63) / 64)),
+      hipLaunchKernelGGL(sym_finish_kernel, dim3(static_cast<unsigned>((a.own_count + 63) / 64)),
                          dim3(64, kParts), 0, stream, sa, a);
       return hipGetLastError();
     }
     const int64_t total = sa.S * a.num_shards;
-    hipLaunchKernelGGL((sym_gather_kernel<IPT>), dim3(static_cast<unsigned>((total + 63) / 64)), dim3(64, kParts), 0,
+    hipLaunchKernelGGL(sym_gather_kernel, dim3(static_cast<unsigned>((total + 63) / 64)), dim3(64, kParts), 0,
                        stream, sa, a.own_shard, a.num_shards, first, out);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
@@ -719,10 +647,16 @@ bool sym_supported(const nbody_mi355x_step_args& a, int64_t* preferred_bytes, in
   return true;
 }
 
+int sym_resolve(const nbody_mi355x_step_args& a) {
+  Plan p;
+  if (!make_plan(a, &p)) return -1;
+  return (p.wave ? 20 : 10) + p.ipt;  // NBODY_MI355X_VARIANT_SYMW* / _SYM*
+}
+
 int sym_step(const nbody_mi355x_step_args& a, hipStream_t stream) {
   Plan p;
   if (!make_plan(a, &p)) {
-    set_error("symmetric step: shard_slots must be a multiple of the block (256 .. 2048 by variant) "
+    set_error("symmetric step: shard_slots must be a multiple of the block (64 .. 2048 by variant) "
               "and the system at least two blocks");
     return NBODY_MI355X_ERR_INVALID;
   }
@@ -752,7 +686,7 @@ int sym_step(const nbody_mi355x_step_args& a, hipStream_t stream) {
   sa.pos = a.pos_cur;
   sa.mass = a.mass;
   sa.R = static_cast<double*>(a.workspace);
-  sa.C = sa.R + static_cast<int64_t>(p.jlocal + p.dsplit * p.jsplit) * 3 * a.shard_slots;
+  sa.C = sa.R + static_cast<int64_t>(p.jlocal + p.rchunks) * 3 * a.shard_slots;
   double* accum = a.num_shards == 1 ? sa.C + batch * 3 * a.shard_slots : nullptr;
   sa.S = a.shard_slots;
   sa.nbs = p.nbs;
@@ -763,22 +697,15 @@ int sym_step(const nbody_mi355x_step_args& a, hipStream_t stream) {
   sa.jsplit = p.jsplit;
   sa.jlocal = p.jlocal;
   sa.r_first = p.jlocal;
-  sa.nR = p.jlocal + p.dsplit * p.jsplit;
+  sa.nR = p.jlocal + p.rchunks;
   sa.d_lo = sa.d_hi = sa.r_base = 0;
   sa.c_base = 1;
   sa.eps2 = a.eps2;
-  const char* no_eq = getenv("NBODY_MI355X_SYM_NOEQ");  // tests: compare the two forms bit for bit
-  sa.no_eq = (no_eq && atoi(no_eq) != 0) ? 1 : 0;
-  const int b = static_cast<int>(batch);
-  hipError_t e;
-  if (a.precision == NBODY_MI355X_FP32) {
-    e = p.ipt == 1 ? launch<1, float>(sa, a, stream, b, accum)
-        : p.ipt == 2 ? launch<2, float>(sa, a, stream, b, accum) : launch<4, float>(sa, a, stream, b, accum);
-  } else {
-    e = p.ipt == 1 ? launch<1, double>(sa, a, stream, b, accum)
-        : p.ipt == 2 ? launch<2, double>(sa, a, stream, b, accum)
-        : p.ipt == 4 ? launch<4, double>(sa, a, stream, b, accum) : launch<8, double>(sa, a, stream, b, accum);
-  }
+  sa.bshift = 0;
+  while ((int64_t{1} << sa.bshift) < p.block) sa.bshift++;
+  sa.per = p.per;
+  sa.no_eq = env_int("NBODY_MI355X_SYM_NOEQ") != 0 ? 1 : 0;  // tests: compare the two forms bit for bit
+  const hipError_t e = launch(p, sa, a, stream, static_cast<int>(batch), accum);
   if (e != hipSuccess) {
     set_error("symmetric step launch: %s", hipGetErrorString(e));
     return NBODY_MI355X_ERR_LAUNCH;
@@ -831,9 +758,7 @@ extern "C" int nbody_mi355x_step_f64_static(const nbody_mi355x_step_args* args, 
   int rc = nbody_internal::check_step_args(args);
   if (rc != NBODY_MI355X_OK) return rc;
   nbody_mi355x_step_args a = *args;
-  const bool sym_variant = a.variant == NBODY_MI355X_VARIANT_SYM || a.variant == NBODY_MI355X_VARIANT_SYM1 ||
-                           a.variant == NBODY_MI355X_VARIANT_SYM2 || a.variant == NBODY_MI355X_VARIANT_SYM4 ||
-                           a.variant == NBODY_MI355X_VARIANT_SYM8;
+  const bool sym_variant = nbody_internal::is_sym_variant(a.variant);
   if (a.variant != 0 && !sym_variant) {
     set_error("step_f64_static: variant %d is a one-sided kernel, which needs no scratch: call nbody_mi355x_step_f64",
               a.variant);

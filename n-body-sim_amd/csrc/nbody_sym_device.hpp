@@ -1,0 +1,255 @@
+// nbody_sym_device.hpp -- device code shared by the two pair-symmetric kernel families
+// (nbody_sym.hip: workgroup tiles, the large systems; nbody_symw.hip: wave tiles, the mid
+// sizes): the launch record, the per-pair arithmetic and the 64-step walk of one j group.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "nbody_device.hpp"
+
+namespace nbody_sym {
+
+using namespace nbody_device;
+
+struct SymArgs {
+  const double* pos;   // all slabs, slab layout
+  const double* mass;  // all slabs, flat
+  double* R;           // [nR][3][S]  i-side sums of the own rows, per distance chunk
+  double* C;           // [Db][3][S]  j-side sums of tile (I, I+d) at row d - c_base, indexed by
+                       //             OWN row I - row0; Db = distances per batch
+  int64_t S;           // slots per slab
+  int nbs;             // blocks per slab = S / B
+  int nb;              // blocks in all = num_shards * nbs
+  int row0;            // first own block row = own_shard * nbs
+  int D;               // largest distance = nb / 2
+  int d_lo, d_hi;      // distances this launch covers, inclusive
+  int dsplit;          // chunks [d_lo, d_hi] is cut into (grid.y)
+  int jsplit;          // parts a tile's j groups are cut into (grid.z): 1, 2, 4 or 8, <= IPT
+  int jlocal;          // the same for the launch of phase 1 (diagonal tiles only); host side only
+  int r_base;          // R chunk of this launch's chunk 0
+  int r_first;         // first R chunk the finishing kernels add (0 = include the local phase's)
+  int nR;              // one past the last R chunk they add
+  int c_base;          // distance stored in row 0 of C for this batch
+  int no_eq;           // 1: never take the equal-mass forms of the tile loop (tests)
+  int bshift;          // log2 of the block size B (finishing kernels: block of a slot = off >> bshift)
+  int per;             // wave tiles only: entries (tile, group) of a row's list per workgroup (multiple of 4)
+  double eps2;
+};
+
+// a pair of coordinates as staged in LDS: {x,y} and {z,m}, in the arithmetic type
+template <typename T>
+struct alignas(2 * sizeof(T)) P2 {
+  T a, b;
+};
+
+__device__ __forceinline__ double rotate_from_next_lane(double v) {
+  // lane l receives lane (l+1) mod 64's value: DPP wave_rol:1 on both halves
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  // (every lane is written, so the "old" operand is never used: pass the source itself
+  // rather than a constant that would cost a v_mov)
+  lo = __builtin_amdgcn_update_dpp(lo, lo, 0x134, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, 0x134, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ float rotate_from_next_lane(float v) {
+  int b = __float_as_int(v);
+  b = __builtin_amdgcn_update_dpp(b, b, 0x134, 0xf, 0xf, false);
+  return __int_as_float(b);
+}
+
+__device__ __forceinline__ double fma_t(double a, double b, double c) { return __builtin_fma(a, b, c); }
+__device__ __forceinline__ float fma_t(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
+// The two weights of one pair from its separation: si = m_j r^-3 (applied to body i) and
+// sj = m_i r^-3 (applied to body j; only computed when WANT_J).
+// double: rsq seed + folded series, r^2 chain seeded with 2^-600 or eps2 (nbody_device.hpp).
+// float (the FP32 variant): v_rsq_f32 is good to an ulp; r^2 == 0 is an explicit select
+// because 2^-600 does not exist in float; and the mass is multiplied in BEFORE the cube is
+// completed, (m y0) (y0 y0), so that r^-3 alone never underflows (r = 1e13 m: 1e-39).
+__device__ __forceinline__ double pair_r3(double dx, double dy, double dz, double eps2, double c15, double c1875) {
+  const double r2 = __builtin_fma(dz, dz, __builtin_fma(dy, dy, __builtin_fma(dx, dx, eps2)));
+  const double y0 = __builtin_amdgcn_rsq(r2);
+  const double u = y0 * y0;
+  const double e = __builtin_fma(-r2, u, 1.0);
+  const double w0 = y0 * u;
+  const double p = __builtin_fma(e, c1875, c15);
+  const double we = w0 * e;
+  return __builtin_fma(we, p, w0);  // r^-3
+}
+__device__ __forceinline__ float pair_r3(float, float, float, float, float, float) { return 0.0f; }  // (double only)
+template <bool WANT_J>
+__device__ __forceinline__ void pair_weights(double dx, double dy, double dz, double mj, double mi, double eps2,
+                                             double c15, double c1875, double* si, double* sj) {
+  const double s0 = pair_r3(dx, dy, dz, eps2, c15, c1875);
+  *si = s0 * mj;
+  if (WANT_J) *sj = s0 * mi;
+}
+template <bool WANT_J>
+__device__ __forceinline__ void pair_weights(float dx, float dy, float dz, float mj, float mi, float eps2,
+                                             float, float, float* si, float* sj) {
+  const float r2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, __builtin_fmaf(dx, dx, eps2)));
+  const float y = __builtin_amdgcn_rsqf(r2);
+  const float y0 = (r2 > 0.0f) ? y : 0.0f;
+  const float y2 = y0 * y0;
+  *si = (mj * y0) * y2;
+  if (WANT_J) *sj = (mi * y0) * y2;
+}
+
+// LDS layout of a staged tile: each group of 64 j bodies takes kGrp = 72 entries, of which
+// entries 64..71 repeat 0..7.  A lane that walks its group from entry r (0..63) can then
+// read 8 consecutive steps at immediate offsets without wrapping, so the inner loop has no
+// address arithmetic (2 integer instructions per 8 steps instead of 7 per 2).
+constexpr int kGrp = 72;
+
+// How the masses enter one pair (workgroup- or wave-uniform, chosen per staged group):
+//   kGeneral   si = m_j r^-3, sj = m_i r^-3: 20 FP64 operations per pair.
+//   kDeferred  (double) every body of the row AND of the staged groups has the one mass
+//              m_ref: both sides take the bare r^-3 and the mass is multiplied in once per
+//              sum instead of once per pair -- the j sums when a wave hands them on, the
+//              i sums (which stay in units of 1/m_ref for the whole row) when the row is
+//              stored: 18 operations per pair.  The benchmark scenes (Plummer sphere,
+//              uniform cube) are equal-mass systems, and so are all but one row of a ring.
+//   kRowUnit   (double) the row has one mass but the staged bodies do not (a padded block,
+//              the ring's planet): the i sums are in units of 1/m_ref, so the i-side weight
+//              is (m_j r^-3) / m_ref; j side as kGeneral.  Rare; 21 operations.
+//   kSameMass  (float) as kDeferred's condition, but the mass stays in the product (r^-3
+//              alone can leave float's range) and one product serves both sides: 19.
+// kDeferred / kRowUnit round once more per sum than kGeneral (the final product with m_ref):
+// results agree to an ulp or two of each sum, not bit for bit.
+enum { kGeneral = 0, kDeferred = 1, kRowUnit = 2, kSameMass = 3 };
+
+// One group of 64 j bodies (LDS entries gb .. gb+71) against this wave's 64*IPT bodies: at
+// step t the lane meets body (lane + t) mod 64 of the group.  SYM: the j-side sums travel
+// with their body through the lanes, one DPP wave rotation per step (6 v_mov_b32_dpp, 3.3
+// cycles each, per IPT pairs); 64 rotations later they are home: lane l holds body l's.
+// (Sending each step's sums to the body's LDS entry with a return-less ds_add_f64 instead
+// was tried: it removes the moves, but an LDS atomic with 64-bit data holds up the SIMD's
+// VALU issue for ~12 cycles, 3 of them cost more than the 6 moves -- tools/ubench_lds.hip,
+// DESIGN.md 3.1b.)  Without SYM (a block against itself) only the i side is kept.
+template <int IPT, bool SYM, int MODE, typename T>
+__device__ __forceinline__ void group_steps(const P2<T>* xy, const P2<T>* zm, int gb, int lane, const T (&xi)[IPT],
+                                            const T (&yi)[IPT], const T (&zi)[IPT], const T (&mi)[IPT],
+                                            T (&ax)[IPT], T (&ay)[IPT], T (&az)[IPT], T eps2, T c15, T c1875,
+                                            T inv_m_ref, T* fxo, T* fyo, T* fzo) {
+  T fx = 0, fy = 0, fz = 0;
+  int rot = lane;
+  // the body of the NEXT step is read while this step's pairs are evaluated: two register
+  // sets used alternately (8 steps per trip: the roles are the same at every trip's start)
+  P2<T> bxy[2], bzm[2];
+  bxy[0] = xy[gb + rot];
+  bzm[0] = zm[gb + rot];
+  for (int t8 = 0; t8 < 8; t8++) {
+    const int rot_next = (rot + 8) & 63;
+    const P2<T>* pxy = xy + gb + rot;
+    const P2<T>* pzm = zm + gb + rot;
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      // (after the last step this reads the group's first body again: a valid address)
+      bxy[(u + 1) & 1] = u < 7 ? pxy[u + 1] : xy[gb + rot_next];
+      bzm[(u + 1) & 1] = u < 7 ? pzm[u + 1] : zm[gb + rot_next];
+      const P2<T> jxy = bxy[u & 1];
+      const P2<T> jzm = bzm[u & 1];
+#pragma unroll
+      for (int k = 0; k < IPT; k++) {
+        const T dx = jxy.a - xi[k];
+        const T dy = jxy.b - yi[k];
+        const T dz = jzm.a - zi[k];
+        T si, sj = 0;
+        if constexpr (MODE == kDeferred) {
+          si = sj = pair_r3(dx, dy, dz, eps2, c15, c1875);
+        } else if constexpr (MODE == kRowUnit) {
+          pair_weights<SYM>(dx, dy, dz, jzm.b, mi[k], eps2, c15, c1875, &si, &sj);
+          si *= inv_m_ref;
+        } else if constexpr (MODE == kSameMass) {
+          pair_weights<false>(dx, dy, dz, jzm.b, mi[k], eps2, c15, c1875, &si, &sj);
+          sj = si;
+        } else {
+          pair_weights<SYM>(dx, dy, dz, jzm.b, mi[k], eps2, c15, c1875, &si, &sj);
+        }
+        ax[k] = fma_t(si, dx, ax[k]);
+        ay[k] = fma_t(si, dy, ay[k]);
+        az[k] = fma_t(si, dz, az[k]);
+        if (SYM) {
+          fx = fma_t(-sj, dx, fx);
+          fy = fma_t(-sj, dy, fy);
+          fz = fma_t(-sj, dz, fz);
+        }
+      }
+      if (SYM) {  // the sums follow their body to the lane that meets it next
+        fx = rotate_from_next_lane(fx);
+        fy = rotate_from_next_lane(fy);
+        fz = rotate_from_next_lane(fz);
+      }
+    }
+    rot = rot_next;
+  }
+  *fxo = fx;
+  *fyo = fy;
+  *fzo = fz;
+}
+
+// first slot of block J in the slab layout: coordinates via *x (y at +S, z at +2S), mass via *m
+template <int B>
+__device__ __forceinline__ void block_base(const SymArgs& a, int J, const double** x, const double** m) {
+  const int slab = J / a.nbs;
+  const int64_t off = static_cast<int64_t>(J - slab * a.nbs) * B;
+  *x = a.pos + static_cast<int64_t>(slab) * 3 * a.S + off;
+  *m = a.mass + static_cast<int64_t>(slab) * a.S + off;
+}
+
+// FP32 variant: where a row's coordinates are measured from.  A float holds a coordinate to
+// 6e-8 of its MAGNITUDE, so narrowing absolute positions makes close pairs of a system that
+// sits far from the origin cancel (a cluster of size 1 at distance 2e3: ulp 1.2e-4).  The
+// reference's float instantiation differences full-precision inputs (particle_simulation.h:
+// 257-270); here the row's bodies and every j body staged against them are taken relative
+// to one point, in double, and only the (small) relative coordinate is narrowed.  The point
+// is the centroid of the row's real bodies -- for bodies in no spatial order that is the
+// system's centre, for sorted ones the block's own neighbourhood.  Padding slots (mass 0 at
+// the origin) are not counted; a centroid that is not finite (NaN / inf input) falls back to
+// 0, i.e. absolute coordinates, so that garbage spreads exactly as before.  Every workgroup
+// of a row adds in the same fixed order: the same origin, bit for bit, run to run.
+__device__ __forceinline__ double uniform(double v) {  // a wave-uniform value into SGPRs
+  return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)),
+                          __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+template <int IPT>
+__device__ __forceinline__ void row_origin(const double* px, const double* pm, int64_t S, int tid, double* ox,
+                                           double* oy, double* oz) {
+  __shared__ double cen[4][4];
+  double sx = 0.0, sy = 0.0, sz = 0.0, cnt = 0.0;
+#pragma unroll
+  for (int k = 0; k < IPT; k++) {
+    const int idx = k * 256 + tid;
+    const double x = px[idx], y = px[S + idx], z = px[2 * S + idx];
+    const bool padding = pm[idx] == 0.0 && x == 0.0 && y == 0.0 && z == 0.0;
+    sx += x; sy += y; sz += z;
+    cnt += padding ? 0.0 : 1.0;
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    sx += __shfl_down(sx, o, 64);
+    sy += __shfl_down(sy, o, 64);
+    sz += __shfl_down(sz, o, 64);
+    cnt += __shfl_down(cnt, o, 64);
+  }
+  if ((tid & 63) == 0) {
+    cen[tid >> 6][0] = sx; cen[tid >> 6][1] = sy; cen[tid >> 6][2] = sz; cen[tid >> 6][3] = cnt;
+  }
+  __syncthreads();
+  const double n = cen[0][3] + cen[1][3] + cen[2][3] + cen[3][3];
+  const double cx = (cen[0][0] + cen[1][0] + cen[2][0] + cen[3][0]) / n;
+  const double cy = (cen[0][1] + cen[1][1] + cen[2][1] + cen[3][1]) / n;
+  const double cz = (cen[0][2] + cen[1][2] + cen[2][2] + cen[3][2]) / n;
+  const bool ok = n > 0.0 && (cx - cx == 0.0) && (cy - cy == 0.0) && (cz - cz == 0.0);
+  // workgroup-uniform: kept in scalar registers (the float IPT = 4 build sits at the VGPR
+  // count that still allows two waves per SIMD; six more VGPRs halve its occupancy)
+  *ox = uniform(ok ? cx : 0.0);
+  *oy = uniform(ok ? cy : 0.0);
+  *oz = uniform(ok ? cz : 0.0);
+}
+
+
+// nbody_symw.hip: launches sym_wave_kernel<ipt, float|double> (ipt 1, 2, 4; 8 in double only)
+hipError_t launch_wave_tiles(int ipt, bool fp32, const SymArgs& sa, dim3 grid, hipStream_t stream);
+
+}  // namespace nbody_sym

@@ -1,0 +1,240 @@
+// nbody_symw.hip -- the pair-symmetric small step with WAVE tiles: the mid-size systems
+// (about 8 000 .. 100 000 bodies on a GPU), where a launch of workgroup tiles (nbody_sym.hip)
+// is a few hundred big work items on 1024 SIMDs -- mostly ramp and tail -- and smaller
+// workgroup tiles pay for it with 6 DPP moves per pair instead of per 8.
+//
+// Same arithmetic, same workspace layout, same finishing kernels as nbody_sym.hip; what
+// differs is who shares what:
+//   * a block is 64*IPT slots (64 .. 512); ALL FOUR waves of a workgroup hold the same block
+//     row in registers (IPT bodies per lane), so IPT -- the number of pairs one LDS read and
+//     one set of DPP moves serve -- no longer fixes the size of a work item;
+//   * the work of row I is the list of its (tile, group) entries: tiles (I, I+d), d = 0 .. D,
+//     each IPT groups of 64 j bodies.  Workgroup (I, c) takes `per` consecutive entries, its
+//     wave w every fourth of them.  A wave stages its group in its OWN 72 LDS entries (no
+//     workgroup barrier anywhere in the loop), walks it in 64 rotation steps (group_steps)
+//     and STORES the group's j-side sums straight to C[d][I][group] -- each (row, group) pair
+//     is met by exactly one wave, so nothing is added across waves on the j side;
+//   * the i-side sums of the 4 waves are added through LDS in wave order at the end and
+//     stored once per workgroup to R[c][I].
+// Work items are 64 x 64*IPT pairs (a few microseconds) instead of whole tiles; with ~16
+// workgroups per CU the hardware's dynamic dispatch levels the load to within one item.
+// The price is C traffic that grows as N^2 / (64*IPT) (each j sum is stored after meeting
+// 64*IPT bodies instead of 256*IPT): that is why the large systems keep workgroup tiles.
+// No atomics: bit-reproducible run to run.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "nbody_sym_device.hpp"
+
+namespace nbody_sym {
+
+namespace {
+
+// float only: the centroid of the row's real bodies (see row_origin, nbody_sym_device.hpp);
+// here every wave holds the whole row, so the sum is a wave reduction and needs no LDS.
+template <int IPT>
+__device__ __forceinline__ void wave_origin(const double* px, const double* pm, int64_t S, int lane, double* ox,
+                                            double* oy, double* oz) {
+  double sx = 0.0, sy = 0.0, sz = 0.0, cnt = 0.0;
+#pragma unroll
+  for (int k = 0; k < IPT; k++) {
+    const int idx = k * 64 + lane;
+    const double x = px[idx], y = px[S + idx], z = px[2 * S + idx];
+    const bool padding = pm[idx] == 0.0 && x == 0.0 && y == 0.0 && z == 0.0;
+    sx += x; sy += y; sz += z;
+    cnt += padding ? 0.0 : 1.0;
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    sx += __shfl_down(sx, o, 64);
+    sy += __shfl_down(sy, o, 64);
+    sz += __shfl_down(sz, o, 64);
+    cnt += __shfl_down(cnt, o, 64);
+  }
+  const double n = uniform(cnt);
+  const double cx = uniform(sx) / n, cy = uniform(sy) / n, cz = uniform(sz) / n;
+  const bool ok = n > 0.0 && (cx - cx == 0.0) && (cy - cy == 0.0) && (cz - cz == 0.0);
+  *ox = ok ? cx : 0.0;
+  *oy = ok ? cy : 0.0;
+  *oz = ok ? cz : 0.0;
+}
+
+template <int IPT, typename T>
+__global__ __launch_bounds__(256) void sym_wave_kernel(const SymArgs a) {
+  constexpr int B = 64 * IPT;
+  constexpr bool kDouble = sizeof(T) == sizeof(double);
+  __shared__ P2<T> xy[4][kGrp];
+  __shared__ P2<T> zm[4][kGrp];
+  __shared__ double red[3][3][B];  // the i-side sums of waves 1 .. 3
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int il = blockIdx.x, c = blockIdx.y;  // own row (local index), chunk of its list
+  const int I = a.row0 + il;
+  const int64_t S = a.S;
+  // double: 2^-600 stands in for "no softening" (nbody_device.hpp); float: plain 0 + a select
+  const T eps2 = static_cast<T>((a.eps2 > 0.0) ? a.eps2 : (kDouble ? kTinyR2 : 0.0));
+  T c15 = static_cast<T>(1.5), c1875 = static_cast<T>(1.875);
+  asm volatile("" : "+v"(c15), "+v"(c1875));
+
+  T xi[IPT], yi[IPT], zi[IPT], mi[IPT], ax[IPT], ay[IPT], az[IPT];
+  double ox = 0.0, oy = 0.0, oz = 0.0;  // float only: see wave_origin
+  {
+    const double *px, *pm;
+    block_base<B>(a, I, &px, &pm);
+    if constexpr (!kDouble) wave_origin<IPT>(px, pm, S, lane, &ox, &oy, &oz);
+#pragma unroll
+    for (int k = 0; k < IPT; k++) {
+      const int idx = k * 64 + lane;
+      if constexpr (!kDouble) {
+        xi[k] = static_cast<T>(px[idx] - ox);
+        yi[k] = static_cast<T>(px[S + idx] - oy);
+        zi[k] = static_cast<T>(px[2 * S + idx] - oz);
+      } else {
+        xi[k] = static_cast<T>(px[idx]);
+        yi[k] = static_cast<T>(px[S + idx]);
+        zi[k] = static_cast<T>(px[2 * S + idx]);
+      }
+      mi[k] = static_cast<T>(pm[idx]);
+      ax[k] = ay[k] = az[k] = 0;
+    }
+  }
+  // do all bodies of this row have one (finite, non-zero) mass?  Every wave holds the whole
+  // row: a wave-uniform answer that is the same in all four.
+  const T m_ref = __shfl(mi[0], 0, 64);
+  const T inv_probe = 1 / m_ref;  // not 0, inf or NaN -- nor so small that 1 / m_ref overflows
+  bool row_same = (m_ref != 0) && (m_ref - m_ref == 0) && (inv_probe - inv_probe == 0);
+#pragma unroll
+  for (int k = 0; k < IPT; k++) row_same = row_same && (mi[k] == m_ref);
+  const bool row_uniform = __all(row_same) && !a.no_eq;
+  const T inv_m_ref = row_uniform ? inv_probe : 0;
+
+  // this launch's part of the row's list: distances d_lo .. dh, IPT entries each
+  int dh = a.d_hi;
+  if (2 * dh == a.nb && I >= a.nb / 2) dh--;  // the antipodal tile belongs to the low rows
+  const int n_entries = (dh - a.d_lo + 1) * IPT;
+  const int e_begin = c * a.per;
+  const int e_end = e_begin + a.per < n_entries ? e_begin + a.per : n_entries;
+
+  P2<T>* wxy = xy[w];
+  P2<T>* wzm = zm[w];
+  for (int e = e_begin + w; e < e_end; e += 4) {
+    const int d = a.d_lo + e / IPT, g = e % IPT;
+    int J = I + d;
+    if (J >= a.nb) J -= a.nb;
+    const double *px, *pm;
+    block_base<B>(a, J, &px, &pm);
+    const int idx = g * 64 + lane;
+    P2<T> vxy, vzm;
+    if constexpr (!kDouble) {  // relative to the row's origin, narrowed after
+      vxy = P2<T>{static_cast<T>(px[idx] - ox), static_cast<T>(px[S + idx] - oy)};
+      vzm = P2<T>{static_cast<T>(px[2 * S + idx] - oz), static_cast<T>(pm[idx])};
+    } else {
+      vxy = P2<T>{static_cast<T>(px[idx]), static_cast<T>(px[S + idx])};
+      vzm = P2<T>{static_cast<T>(px[2 * S + idx]), static_cast<T>(pm[idx])};
+    }
+    // (the wave's previous group has been read to the end: LDS serves a wave's accesses in order)
+    wxy[lane] = vxy;
+    wzm[lane] = vzm;
+    if (lane < kGrp - 64) {  // the group's first entries again behind its end
+      wxy[lane + 64] = vxy;
+      wzm[lane + 64] = vzm;
+    }
+    const bool equal_mass = __all(vzm.b == m_ref) && row_uniform;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    T fx = 0, fy = 0, fz = 0;
+#define NBODY_GROUP(SYM_, MODE_)                                                                                  \
+  group_steps<IPT, SYM_, MODE_, T>(wxy, wzm, 0, lane, xi, yi, zi, mi, ax, ay, az, eps2, c15, c1875, inv_m_ref, &fx, \
+                                   &fy, &fz)
+    if (d != 0) {
+      if (kDouble) {
+        if (equal_mass) {
+          NBODY_GROUP(true, kDeferred);
+          fx *= m_ref;
+          fy *= m_ref;
+          fz *= m_ref;
+        } else if (row_uniform) {
+          NBODY_GROUP(true, kRowUnit);
+        } else {
+          NBODY_GROUP(true, kGeneral);
+        }
+      } else {
+        if (equal_mass) NBODY_GROUP(true, kSameMass);
+        else NBODY_GROUP(true, kGeneral);
+      }
+      // 64 rotations later the sums are home: lane l holds body l of the group
+      double* Cd = a.C + static_cast<int64_t>(d - a.c_base) * 3 * S + static_cast<int64_t>(il) * B;
+      Cd[idx] = fx;
+      Cd[S + idx] = fy;
+      Cd[2 * S + idx] = fz;
+    } else {  // a group of the row's own block: i side only, every ordered pair
+      if (kDouble && row_uniform) NBODY_GROUP(false, kRowUnit);
+      else NBODY_GROUP(false, kGeneral);
+    }
+#undef NBODY_GROUP
+    __builtin_amdgcn_wave_barrier();
+  }
+
+  // the four waves' i-side sums, added in wave order
+  if (w > 0) {
+#pragma unroll
+    for (int k = 0; k < IPT; k++) {
+      red[w - 1][0][k * 64 + lane] = ax[k];
+      red[w - 1][1][k * 64 + lane] = ay[k];
+      red[w - 1][2][k * 64 + lane] = az[k];
+    }
+  }
+  __syncthreads();
+  if (w == 0) {
+    double* Rs = a.R + static_cast<int64_t>(a.r_base + c) * 3 * S + static_cast<int64_t>(il) * B;
+#pragma unroll
+    for (int k = 0; k < IPT; k++) {
+      const int idx = k * 64 + lane;
+      double x = ax[k], y = ay[k], z = az[k];
+#pragma unroll
+      for (int q = 0; q < 3; q++) {
+        x += red[q][0][idx];
+        y += red[q][1][idx];
+        z += red[q][2][idx];
+      }
+      if (kDouble && row_uniform) {  // back from units of 1/m_ref
+        x *= m_ref;
+        y *= m_ref;
+        z *= m_ref;
+      }
+      Rs[idx] = x;
+      Rs[S + idx] = y;
+      Rs[2 * S + idx] = z;
+    }
+  }
+}
+
+template <int IPT, typename T>
+hipError_t launch_one(const SymArgs& sa, dim3 grid, hipStream_t stream) {
+  hipLaunchKernelGGL((sym_wave_kernel<IPT, T>), grid, dim3(256), 0, stream, sa);
+  return hipGetLastError();
+}
+
+}  // namespace
+
+hipError_t launch_wave_tiles(int ipt, bool fp32, const SymArgs& sa, dim3 grid, hipStream_t stream) {
+  if (fp32) {
+    switch (ipt) {
+      case 1: return launch_one<1, float>(sa, grid, stream);
+      case 2: return launch_one<2, float>(sa, grid, stream);
+      case 4: return launch_one<4, float>(sa, grid, stream);
+      default: return hipErrorInvalidValue;
+    }
+  }
+  switch (ipt) {
+    case 1: return launch_one<1, double>(sa, grid, stream);
+    case 2: return launch_one<2, double>(sa, grid, stream);
+    case 4: return launch_one<4, double>(sa, grid, stream);
+    case 8: return launch_one<8, double>(sa, grid, stream);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+}  // namespace nbody_sym

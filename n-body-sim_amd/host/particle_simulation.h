@@ -386,6 +386,14 @@ class ParticleSimulation {
     if (rc != NBODY_MI355X_OK) return Failure(rc, nullptr);
     rc = nbody_mi355x_upload(sim, state_[cur_].data(), mass_.data());
     if (rc != NBODY_MI355X_OK) return Failure(rc, sim);
+    {  // say so when the library had to fall back to the slower kernel family
+      int32_t variant = 0;
+      int64_t workspace_bytes = 0;
+      if (nbody_mi355x_kernel_in_use(sim, &variant, &workspace_bytes) == NBODY_MI355X_OK && workspace_bytes == 0 &&
+          num_particles_ > NBODY_MI355X_WAVE_MAX_BODIES && variant >= 1 && variant <= 6)
+        std::cout << "MI355X: no room on the device for the pair-symmetric kernels' workspace; running the "
+                     "one-sided kernel (variant " << variant << ", about half the rate)." << std::endl;
+    }
 
     SaveFirstStep();
     IntervallTimer sim_timer;

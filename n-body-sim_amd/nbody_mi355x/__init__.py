@@ -54,8 +54,11 @@ class StepArgs(C.Structure):
 
 VARIANT_WAVE, VARIANT_TINY = 7, 8
 STATIC_SCRATCH_BYTES = 134217728   # NBODY_MI355X_STATIC_SCRATCH_BYTES
-WAVE_MAX_BODIES = 7168   # NBODY_MI355X_WAVE_MAX_BODIES: below, whole FP64 steps take the wave kernels
+WAVE_MAX_BODIES = 4096   # NBODY_MI355X_WAVE_MAX_BODIES: below, whole FP64 steps take the wave kernels
 VARIANT_SYM, VARIANT_SYM1, VARIANT_SYM2, VARIANT_SYM4, VARIANT_SYM8 = 10, 11, 12, 14, 18
+VARIANT_SYMW1, VARIANT_SYMW2, VARIANT_SYMW4, VARIANT_SYMW8 = 21, 22, 24, 28   # pair-symmetric, wave tiles
+SYM_VARIANTS = (VARIANT_SYM, VARIANT_SYM1, VARIANT_SYM2, VARIANT_SYM4, VARIANT_SYM8,
+                VARIANT_SYMW1, VARIANT_SYMW2, VARIANT_SYMW4, VARIANT_SYMW8)
 
 
 class Config(C.Structure):
@@ -75,6 +78,7 @@ SYMBOLS = {
     "nbody_mi355x_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "nbody_mi355x_step_f64": (C.c_int, [C.POINTER(StepArgs), _P]),
     "nbody_mi355x_step_f64_static": (C.c_int, [C.POINTER(StepArgs), _P]),
+    "nbody_mi355x_step_variant": (C.c_int, [C.POINTER(StepArgs), C.POINTER(C.c_int32)]),
     "nbody_mi355x_step_workspace_bytes": (C.c_int, [C.POINTER(StepArgs), C.POINTER(C.c_int64)]),
     "nbody_mi355x_pack_f64": (C.c_int, [_P, C.c_int64, _P, _P, C.c_int64, _P]),
     "nbody_mi355x_unpack_f64": (C.c_int, [_P, _P, C.c_int64, C.c_int64, _P, _P]),
@@ -91,6 +95,7 @@ SYMBOLS = {
     "nbody_mi355x_host_free": (C.c_int, [_P]),
     "nbody_mi355x_download": (C.c_int, [_P, _P]),
     "nbody_mi355x_energy": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "nbody_mi355x_kernel_in_use": (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
     "nbody_mi355x_last_run_seconds": (C.c_int, [_P, C.POINTER(C.c_double)]),
     "nbody_mi355x_ic_plummer": (C.c_int, [C.c_int64, C.c_uint64, C.c_double, _P, _P]),
     "nbody_mi355x_ic_uniform_cube": (C.c_int, [C.c_int64, C.c_uint64, C.c_double, _P, _P]),
@@ -248,6 +253,12 @@ class Simulation:
         ke, pe = C.c_double(), C.c_double()
         check(lib().nbody_mi355x_energy(self._h, C.byref(ke), C.byref(pe)))
         return ke.value, pe.value
+
+    def kernel_in_use(self):
+        """(variant, workspace_bytes): the kernel build a small step runs, the pair-symmetric workspace held."""
+        v, b = C.c_int32(), C.c_int64()
+        check(lib().nbody_mi355x_kernel_in_use(self._h, C.byref(v), C.byref(b)))
+        return v.value, b.value
 
     def last_run_seconds(self) -> float:
         s = C.c_double()

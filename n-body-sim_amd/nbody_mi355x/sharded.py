@@ -33,11 +33,9 @@ import ctypes as C
 import numpy as np
 import torch
 
-from . import (FP64, G_REFERENCE, TILE, VARIANT_SYM, VARIANT_SYM1, VARIANT_SYM2, VARIANT_SYM4, VARIANT_SYM8, StepArgs,
-               check, lib, round_up)
+from . import FP64, G_REFERENCE, SYM_VARIANTS, TILE, VARIANT_SYM, VARIANT_SYM8, VARIANT_SYMW8, StepArgs, check, lib, round_up
 
 SYM_MIN_BODIES = 2048  # as kSymMinBodies in csrc/nbody_kernels.hip
-SYM_VARIANTS = (VARIANT_SYM, VARIANT_SYM1, VARIANT_SYM2, VARIANT_SYM4, VARIANT_SYM8)
 
 
 def shard_counts(n: int, world: int):
@@ -99,7 +97,11 @@ class ShardedNBody:
         # large systems: whole 1024- or 2048-body blocks, so that the pair-symmetric kernels apply
         # with their largest block
         big = max(self.counts)
-        self.S = S = round_up(big, 2048 if big >= 65536 else (1024 if big >= 8192 else TILE))
+        variant = getattr(self.backend, "variant", None)
+        unit = 2048 if (big >= 65536 or variant == VARIANT_SYM8) else (1024 if big >= 8192 else TILE)
+        if variant == VARIANT_SYMW8:
+            unit = max(unit, 512)
+        self.S = S = round_up(big, unit)
 
         # host image of the slab layout; padding slots: mass 0 at the origin
         pos = np.zeros((world, 3, S))
@@ -122,7 +124,6 @@ class ShardedNBody:
         # system is large enough and their workspace fits; otherwise the one-sided kernel
         self.workspace = None
         self.acc_all = None
-        variant = getattr(self.backend, "variant", None)
         if (use_workspace and hasattr(self.backend, "workspace_bytes") and self.device.type == "cuda"
                 and (variant in SYM_VARIANTS or (variant == 0 and self.n >= SYM_MIN_BODIES))):
             need = self.backend.workspace_bytes(S, world)

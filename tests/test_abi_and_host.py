@@ -120,3 +120,35 @@ def test_python_constants_mirror_the_header():
     assert int(defs["VARIANT_WAVE"]) == nb.VARIANT_WAVE and int(defs["VARIANT_TINY"]) == nb.VARIANT_TINY
     assert int(defs["VARIANT_SYM"]) == nb.VARIANT_SYM and int(defs["VARIANT_SYM8"]) == nb.VARIANT_SYM8
     assert int(defs["TILE"]) == nb.TILE and float(defs["G_REFERENCE"]) == nb.G_REFERENCE
+
+
+def test_step_variant_reports_the_kernel_choice_without_a_gpu():
+    """nbody_mi355x_step_variant is the read-only view of the one place the kernel is chosen
+    (csrc/nbody_kernels.hip: resolve_variant): no launch, so it runs here.  Without a workspace
+    a large system gets a ONE-SIDED build -- that is how a caller sees the fallback."""
+    import ctypes as C
+    L = nb.lib()
+
+    def variant_of(n, workspace_bytes=0, variant=0, precision=nb.FP64, shards=1):
+        a = nb.StepArgs()
+        a.pos_cur, a.pos_next, a.mass, a.vel = 8, 16, 8, 8    # never dereferenced
+        S = nb.round_up(n, 2048 if n >= 65536 else (1024 if n >= 8192 else nb.TILE))
+        a.shard_slots, a.num_shards, a.own_count, a.j0_end = S, shards, n, n
+        a.precision, a.variant = precision, variant
+        if workspace_bytes:
+            a.workspace, a.workspace_bytes = 8, workspace_bytes
+        v = C.c_int32(-1)
+        nb.check(L.nbody_mi355x_step_variant(C.byref(a), C.byref(v)))
+        return v.value
+
+    big = 1 << 40
+    assert variant_of(500) == nb.VARIANT_WAVE and variant_of(nb.WAVE_MAX_BODIES, big) == nb.VARIANT_WAVE
+    assert variant_of(100000) in (1, 2) and variant_of(1048576) == 2          # no workspace: one-sided
+    assert variant_of(8192, big) == nb.VARIANT_SYMW2 and variant_of(16384, big) == nb.VARIANT_SYMW4
+    assert variant_of(65536, big) == nb.VARIANT_SYMW8 and variant_of(1048576, big) == nb.VARIANT_SYM8
+    assert variant_of(65536, big, precision=nb.FP32) == nb.VARIANT_SYMW4      # (no 512-body float build)
+    assert variant_of(65536, 4096) in (1, 2)                                  # workspace below the minimum
+    assert variant_of(20000, big, variant=nb.VARIANT_SYM4) == nb.VARIANT_SYM4
+    assert variant_of(20000, 0, variant=3) == 3
+    a = nb.StepArgs()
+    assert L.nbody_mi355x_step_variant(C.byref(a), C.byref(C.c_int32())) == nb.ERR_INVALID

@@ -121,7 +121,7 @@ def test_softening_matches_direct_formula():
     assert vec_rel(out[0, :, 6:9], a) <= 1e-13
 
 
-@pytest.mark.parametrize("variant", [0, 2, 11, 12, 14])
+@pytest.mark.parametrize("variant", [0, 2, 11, 12, 14, 21, 22, 24])
 def test_fp32_variant_within_1e_4(variant):
     """north_star: FP32 variant within 1e-4 after 100 steps, one-sided (2) and pair-symmetric."""
     g = load_golden("g4_plummer_4096")
@@ -255,11 +255,13 @@ def test_error_behaviour():
 @pytest.mark.parametrize("variant,n", [(14, 4096), (12, 4096), (12, 3000), (14, 10000), (14, 11000),
                                        (14, 2048), (12, 1024), (0, 20000), (11, 700), (11, 5000),
                                        (10, 9000), (10, 40000), (18, 4096), (18, 6000), (18, 11000),
-                                       (18, 70000), (0, 70000)])
+                                       (18, 70000), (0, 70000),
+                                       (21, 128), (21, 700), (21, 5000), (22, 3000), (22, 4096), (24, 2048),
+                                       (24, 10000), (24, 40000), (28, 1024), (28, 6000), (28, 11000), (28, 70000)])
 def test_symmetric_kernels_against_oracle(variant, n):
     """Newton's-third-law kernels (each unordered pair once; even and odd block counts,
     ragged last block, the smallest legal systems; 18 = 2048-body blocks, staged in two
-    halves) against the oracle's ordered-pair sums."""
+    halves; 21 .. 28 = wave tiles, blocks of 64 .. 512 bodies) against the oracle's ordered-pair sums."""
     p, m = nb.ic_plummer(n, 300 + n)
     _, ref = ol.simulate(p, m, 1, 10, 1e-3, threads=16)
     _, out = gpu_simulate(p, m, 1, 10, 1e-3, variant=variant)
@@ -427,14 +429,17 @@ def test_equal_mass_forms_agree_with_general_form(precision, monkeypatch):
 
 
 @pytest.mark.parametrize("n", [63, 64, 65, 1023, 1024, 1025, 2047, 2048, 2049, 2305, 2559, 2560, 2561, 4095,
-                               4097, 7167, 7168, 7169, 8191, 8193, 9217, 16383, 16385, 24577,
-                               32767, 32769, 49153, 65535, 65537, 67585, 131073])
+                               4096, 4097, 4353, 5000, 7168, 7169, 8191, 8193, 9217, 10240, 11264, 11265, 12289,
+                               16383, 16385, 20480, 24577, 28672, 32767, 32769, 40960, 48128, 49153, 57344,
+                               65535, 65537, 67585, 131073])
 def test_automatic_plan_at_every_boundary(n):
     """The library's own choice (variant 0) one body either side of everything that switches
-    it: one wave for the whole system (64), the wave kernels' shapes (1024, 2560) and their end
-    (NBODY_MI355X_WAVE_MAX_BODIES = 7168, the pair-symmetric kernels beyond), the slot rounding
-    (256 / 1024 / 2048 at 8192 and 65 536), the block-size thresholds of make_plan
-    (csrc/nbody_sym.hip) and ragged last blocks.  Mixed masses (general form) and equal masses (deferred form), 3 small steps."""
+    it: one wave for the whole system (64), the wave-per-body kernels' shapes (1024, 2560) and
+    their end (NBODY_MI355X_WAVE_MAX_BODIES = 4096, the pair-symmetric kernels beyond), the slot
+    rounding (256 / 1024 / 2048 at 8192 and 65 536), the sizes at which the launch model of the
+    wave tiles (csrc/nbody_sym.hip: plan_wave) changes block size or chunking -- powers of two
+    and sizes in between -- and ragged last blocks.  Mixed masses (general form) and equal
+    masses (deferred form), 3 small steps."""
     rng = np.random.default_rng(n)
     p, m = nb.ic_plummer(n, 900 + n)
     for masses in (m, m * rng.uniform(0.5, 2.0, n)):
@@ -585,3 +590,17 @@ def test_fp32_symmetric_far_from_the_origin_100_steps(scene):
     scale = np.linalg.norm(ref[0, :, 6:9], axis=1).max()
     assert np.abs(out[0, :, 6:9] - ref[0, :, 6:9]).max() <= FP32_ACC_TOL * scale
     assert rel_pos_err(out[0, :, :3], ref[0, :, :3]) > 1e-14   # it is the float kernel
+
+
+@pytest.mark.parametrize("n,kw,expect", [(2, {}, nb.VARIANT_TINY), (500, {}, nb.VARIANT_WAVE), (4096, {}, nb.VARIANT_WAVE),
+                                         (8192, {}, nb.VARIANT_SYMW2), (65536, {}, nb.VARIANT_SYMW8),
+                                         (300000, {}, nb.VARIANT_SYM8), (300000, {"variant": 2}, 2),
+                                         (30000, {"devices": [0, 0]}, nb.VARIANT_SYMW4)])
+def test_kernel_in_use_query(n, kw, expect):
+    """The handle says which kernel build its small steps run and what workspace it holds
+    (nbody_mi355x_kernel_in_use): SimulateMI355X() prints a line when a large system had to
+    fall back to the one-sided kernels for lack of room."""
+    with nb.Simulation(n, 1e-3, **kw) as sim:
+        variant, ws = sim.kernel_in_use()
+    assert variant == expect
+    assert (ws > 0) == (variant in nb.SYM_VARIANTS)

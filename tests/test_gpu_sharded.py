@@ -87,12 +87,16 @@ def test_pack_unpack_roundtrip():
     assert torch.equal(pos[:, :n], aos[:, :3].T) and torch.all(pos[:, n:] == 0)
 
 
-@pytest.mark.parametrize("world,n", [(2, 20000), (4, 16384), (3, 30000), (8, 65536)])
-def test_symmetric_multi_slab_equals_oracle(world, n):
+@pytest.mark.parametrize("world,n,variant", [(2, 20000, 0), (4, 16384, 0), (3, 30000, 0), (8, 65536, 0),
+                                             (2, 20000, nb.VARIANT_SYMW4), (3, 30000, nb.VARIANT_SYMW2),
+                                             (4, 65536, nb.VARIANT_SYMW8), (5, 1500, nb.VARIANT_SYMW1)])
+def test_symmetric_multi_slab_equals_oracle(world, n, variant):
     """Pair-symmetric kernels over several slabs: every fake rank computes partial sums
     for ALL slots, the loop-back 'reduce-scatter' adds them, each rank integrates its slab."""
     p, m = nb.ic_plummer(n, 13)
-    sims = [ShardedNBody(p, m, 1e-3, rank=r, world=world, device="cuda") for r in range(world)]
+    from nbody_mi355x.sharded import HipBackend
+    sims = [ShardedNBody(p, m, 1e-3, rank=r, world=world, device="cuda", backend=HipBackend(variant=variant))
+            for r in range(world)]
     assert all(s.workspace is not None and s.acc_all is not None for s in sims)
     grp = LoopbackGroup(sims)
     steps = 4
@@ -152,12 +156,13 @@ def test_config4_one_gpu_vs_eight_ranks_agree():
     assert (num / np.linalg.norm(ref[:, 3:6], axis=1)).max() <= 1e-12
 
 
-@pytest.mark.parametrize("variant", [nb.VARIANT_SYM4, nb.VARIANT_SYM8])
+@pytest.mark.parametrize("variant", [nb.VARIANT_SYM4, nb.VARIANT_SYM8, nb.VARIANT_SYMW2, nb.VARIANT_SYMW8])
 def test_symmetric_phases_equal_whole(variant):
     """phase 1 (diagonal tiles, own slab only) + phase 2 (the rest) == phase 0."""
     n, world, rank = 40000, 4, 2
     p, m = nb.ic_plummer(n, 21)
-    s = ShardedNBody(p, m, 1e-3, rank=rank, world=world, device="cuda")
+    from nbody_mi355x.sharded import HipBackend
+    s = ShardedNBody(p, m, 1e-3, rank=rank, world=world, device="cuda", backend=HipBackend(variant=variant))
     common = dict(pos_cur=s.pos[0], pos_next=s.pos[1], mass=s.mass, vel=s.vel, S=s.S, world=world, rank=rank,
                   count=s.count, dt=s.dt, G=s.G, eps2=0.0)
     kw = dict(acc_in=None, snapshot=None, ranges=((0, 0), (0, 0)), workspace=s.workspace, variant=variant, **common)
