@@ -56,11 +56,25 @@ typedef enum {
 /* Time integrator fused into the step's epilogue.
  * EULER: the reference's forward Euler, v' = v + dt a, r' = r + dt v (OLD v)
  *        (ref: particle_simulation.h:288-300) -- the parity path.
- * KICK_DRIFT: r' = r + dt v' (NEW v): the symplectic (semi-implicit) Euler step, i.e.
- *        leapfrog with velocities read half a step late; same force kernel, same
- *        cost, bounded energy error.  Not in the reference. */
+ * KICK_DRIFT: r' = r + dt v' (NEW v): the symplectic (semi-implicit) Euler step.  First
+ *        order like EULER, but its energy error stays bounded; same kernel, same cost.
+ * KDK:   kick-drift-kick leapfrog, second order, still ONE force evaluation per small step:
+ *        v += dt/2 a(r);  r += dt v;  v += dt/2 a(r')   with a(r') carried over to the next
+ *        step's first kick.  Neither is in the reference.
+ * Level 2 (nbody_mi355x_config.integrator) takes EULER, KICK_DRIFT or KDK and sequences the
+ * pieces itself.  At level 1 a KDK small step is made of
+ *   nbody_mi355x_kdk_drift_f64: v += (dt/2 a) G from args->kdk_acc, pos_next = pos_cur + dt v
+ *        -> exchange positions, swap buffers ->
+ *   nbody_mi355x_step_f64 with integrator = KDK: forces at pos_cur, v += (dt/2 a) G, the raw
+ *        sums stored to args->kdk_acc, snapshot {r, v, a G}; positions are not written;
+ * or, between two small steps, of ONE call with integrator = KDK_CONTINUE, whose epilogue is
+ * that second kick followed by the next step's first kick and drift (pos_next written; a
+ * snapshot holds the synchronised {r, v, a G} at pos_cur).  kdk_acc of the very first step is
+ * obtained by a KDK call with dt = 0. */
 #define NBODY_MI355X_EULER 0
 #define NBODY_MI355X_KICK_DRIFT 1
+#define NBODY_MI355X_KDK 2
+#define NBODY_MI355X_KDK_CONTINUE 3 /* level 1 only */
 
 /* Tile width of the j loop; shard_slots must be a multiple of it. */
 #define NBODY_MI355X_TILE 256
@@ -123,8 +137,11 @@ typedef struct {
                              sums for EVERY slot, to be reduce-scattered and
                              integrated by a one-sided step with acc_in and
                              empty j ranges.                                   */
-  int32_t integrator;     /* NBODY_MI355X_EULER (the reference's, default) or
-                             NBODY_MI355X_KICK_DRIFT                           */
+  int32_t integrator;     /* NBODY_MI355X_EULER (the reference's, default),
+                             _KICK_DRIFT, _KDK or _KDK_CONTINUE                */
+  double* kdk_acc;        /* KDK / KDK_CONTINUE: if not NULL, [3][shard_slots] own slab,
+                             receives the raw sums (no G) the kick was made with; the
+                             drift (nbody_mi355x_kdk_drift_f64) reads them       */
 } nbody_mi355x_step_args;
 
 #define NBODY_MI355X_VARIANT_WAVE  7 /* one-sided, a wave per 1, 2 or 4 bodies: the default for whole
@@ -152,6 +169,12 @@ typedef struct {
  * maths as MakeSmallStep, particle_simulation.h:248-322).  Asynchronous on
  * `stream` (a hipStream_t, NULL = the default stream). */
 int nbody_mi355x_step_f64(const nbody_mi355x_step_args* args, void* stream);
+
+/* First half of a kick-drift-kick small step for the own slab's bodies (see the integrator
+ * notes above): vel += (dt/2 * kdk_acc) * G, pos_next = pos_cur + dt * vel.  Fields read:
+ * pos_cur, pos_next, vel, kdk_acc, shard_slots, num_shards, own_shard, own_count, dt, G.
+ * O(N), memory-bound.  Sits beside the reference's Euler update, particle_simulation.h:282-300. */
+int nbody_mi355x_kdk_drift_f64(const nbody_mi355x_step_args* args, void* stream);
 
 /* Which kernel build nbody_mi355x_step_f64 runs for these args: *variant = a concrete
  * NBODY_MI355X_VARIANT_* -- SYM1 .. SYM8 / SYMW1 .. SYMW8 (pair-symmetric, block size
@@ -219,7 +242,7 @@ typedef struct {
   int32_t host_is_float; /* 0: host records are double (ParticleSimulation<double,W>),
                             1: float (ParticleSimulation<float,W>)             */
   int32_t variant;       /* as in nbody_mi355x_step_args                       */
-  int32_t integrator;    /* NBODY_MI355X_EULER (default) / NBODY_MI355X_KICK_DRIFT */
+  int32_t integrator;    /* NBODY_MI355X_EULER (default) / _KICK_DRIFT / _KDK     */
   int32_t reserved;
 } nbody_mi355x_config;
 

@@ -82,6 +82,43 @@ __device__ __forceinline__ void integrate_and_store(const nbody_mi355x_step_args
                                                     double ayd, double azd) {
   const int64_t S = a.shard_slots;
   const double vx = a.vel[li], vy = a.vel[S + li], vz = a.vel[2 * S + li];
+  if (a.integrator >= NBODY_MI355X_KDK) {
+    // kick-drift-kick leapfrog: (xi, yi, zi) are the positions AFTER this step's drift, the
+    // sums are a(r'): the second kick completes the step -- {r', v', a} is the synchronised
+    // state -- and KDK_CONTINUE goes straight on with the next step's first kick and drift
+    const double h = 0.5 * a.dt;
+    const double svx = __builtin_fma(h * axd, a.G, vx);
+    const double svy = __builtin_fma(h * ayd, a.G, vy);
+    const double svz = __builtin_fma(h * azd, a.G, vz);
+    if (a.integrator == NBODY_MI355X_KDK_CONTINUE) {
+      const double nvx = __builtin_fma(h * axd, a.G, svx);
+      const double nvy = __builtin_fma(h * ayd, a.G, svy);
+      const double nvz = __builtin_fma(h * azd, a.G, svz);
+      a.vel[li] = nvx;
+      a.vel[S + li] = nvy;
+      a.vel[2 * S + li] = nvz;
+      double* nown = a.pos_next + static_cast<int64_t>(a.own_shard) * 3 * S;
+      nown[li] = __builtin_fma(a.dt, nvx, xi);
+      nown[S + li] = __builtin_fma(a.dt, nvy, yi);
+      nown[2 * S + li] = __builtin_fma(a.dt, nvz, zi);
+    } else {
+      a.vel[li] = svx;
+      a.vel[S + li] = svy;
+      a.vel[2 * S + li] = svz;
+    }
+    if (a.kdk_acc != nullptr) {
+      a.kdk_acc[li] = axd;
+      a.kdk_acc[S + li] = ayd;
+      a.kdk_acc[2 * S + li] = azd;
+    }
+    if (a.snapshot != nullptr) {
+      double* o = a.snapshot + 9 * li;
+      o[0] = xi; o[1] = yi; o[2] = zi;
+      o[3] = svx; o[4] = svy; o[5] = svz;
+      o[6] = axd * a.G; o[7] = ayd * a.G; o[8] = azd * a.G;
+    }
+    return;
+  }
   const double nvx = __builtin_fma(a.dt * axd, a.G, vx);
   const double nvy = __builtin_fma(a.dt * ayd, a.G, vy);
   const double nvz = __builtin_fma(a.dt * azd, a.G, vz);

@@ -47,7 +47,8 @@ int sym_resolve(const nbody_mi355x_step_args& a);
 // in ONE launch of one wave (in place on a.pos_cur / a.vel; a.snapshot, if set, receives the
 // last small step's records).  One slab, FP64, no split ranges.
 constexpr int64_t kTinyMaxBodies = 64;
-int tiny_run(const nbody_mi355x_step_args& a, int64_t substeps, struct ihipStream_t* stream);
+// (integrator KDK: a.kdk_acc carries the sums between calls; kdk_prime: evaluate them first)
+int tiny_run(const nbody_mi355x_step_args& a, int64_t substeps, bool kdk_prime, struct ihipStream_t* stream);
 // nbody_multi.hip: the handle over several shards / GPUs (host records already double)
 struct MultiSim;
 int multi_create(const nbody_mi355x_config& cfg, const int32_t* devices, int32_t num, MultiSim** out);

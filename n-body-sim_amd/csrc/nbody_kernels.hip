@@ -322,7 +322,7 @@ __global__ __launch_bounds__(kTile) void step_wave_kernel(const nbody_mi355x_ste
 // are read back as broadcasts in the reference's order j = 0 .. N-1 (same summation order
 // as MakeSmallStep, particle_simulation.h:256-275).  In place: the state is read from and
 // written back to pos_cur / vel.
-__global__ __launch_bounds__(64) void step_tiny_kernel(const nbody_mi355x_step_args a, int64_t substeps) {
+__global__ __launch_bounds__(64) void step_tiny_kernel(const nbody_mi355x_step_args a, int64_t substeps, int kdk_prime) {
   __shared__ JBody body[2][64];
   const int i = threadIdx.x;
   const int n = static_cast<int>(a.own_count);
@@ -336,15 +336,46 @@ __global__ __launch_bounds__(64) void step_tiny_kernel(const nbody_mi355x_step_a
   double vx = a.vel[ic], vy = a.vel[S + ic], vz = a.vel[2 * S + ic];
   const double m = real ? a.mass[ic] : 0.0;
   const bool kd = a.integrator == NBODY_MI355X_KICK_DRIFT;
+  const bool kdk = a.integrator == NBODY_MI355X_KDK;
+  const double h = 0.5 * a.dt;
   double ax = 0.0, ay = 0.0, az = 0.0;
-  for (int64_t k = 0; k < substeps; k++) {
-    JBody* buf = body[k & 1];
-    buf[i] = JBody{x, y, z, m};
-    __syncthreads();  // (buffer k&1 is next written two small steps on, past the next barrier)
+  // the sums over all bodies at the positions every lane has just published in buf
+  auto forces = [&](const JBody* buf) {
     ax = ay = az = 0.0;
     for (int j = 0; j < n; j++) {
       const JBody b = buf[j];
       pair_f64(x, y, z, b.x, b.y, b.z, b.m, eps2, c15, c1875, ax, ay, az);
+    }
+  };
+  if (kdk) {
+    // kick-drift-kick: a(r) comes in from the previous big step (kdk_acc) or, the first time,
+    // from one extra evaluation; every small step then costs one evaluation, at r'
+    if (kdk_prime) {
+      body[1][i] = JBody{x, y, z, m};
+      __syncthreads();
+      forces(body[1]);
+    } else {
+      ax = a.kdk_acc[ic]; ay = a.kdk_acc[S + ic]; az = a.kdk_acc[2 * S + ic];
+    }
+  }
+  for (int64_t k = 0; k < substeps; k++) {
+    JBody* buf = body[k & 1];
+    if (kdk) {
+      vx = __builtin_fma(h * ax, a.G, vx);
+      vy = __builtin_fma(h * ay, a.G, vy);
+      vz = __builtin_fma(h * az, a.G, vz);
+      x = __builtin_fma(a.dt, vx, x);
+      y = __builtin_fma(a.dt, vy, y);
+      z = __builtin_fma(a.dt, vz, z);
+    }
+    buf[i] = JBody{x, y, z, m};
+    __syncthreads();  // (buffer k&1 is next written two small steps on, past the next barrier)
+    forces(buf);
+    if (kdk) {
+      vx = __builtin_fma(h * ax, a.G, vx);
+      vy = __builtin_fma(h * ay, a.G, vy);
+      vz = __builtin_fma(h * az, a.G, vz);
+      continue;
     }
     // ref: particle_simulation.h:288-300 (see integrate_and_store)
     const double nvx = __builtin_fma(a.dt * ax, a.G, vx);
@@ -359,11 +390,31 @@ __global__ __launch_bounds__(64) void step_tiny_kernel(const nbody_mi355x_step_a
   double* pos = const_cast<double*>(a.pos_cur);
   pos[i] = x; pos[S + i] = y; pos[2 * S + i] = z;
   a.vel[i] = vx; a.vel[S + i] = vy; a.vel[2 * S + i] = vz;
+  if (kdk && a.kdk_acc != nullptr) {
+    a.kdk_acc[i] = ax; a.kdk_acc[S + i] = ay; a.kdk_acc[2 * S + i] = az;
+  }
   if (a.snapshot != nullptr) {
     double* o = a.snapshot + 9 * i;
     o[0] = x; o[1] = y; o[2] = z;
     o[3] = vx; o[4] = vy; o[5] = vz;
     o[6] = ax * a.G; o[7] = ay * a.G; o[8] = az * a.G;
+  }
+}
+
+// ------------------------------------------------------------ kick-drift-kick: the drift
+// vel += (dt/2 * a) * G with the sums the last kick stored, pos_next = pos_cur + dt * vel
+__global__ __launch_bounds__(256) void kdk_drift_kernel(const nbody_mi355x_step_args a) {
+  const int64_t li = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (li >= a.own_count) return;
+  const int64_t S = a.shard_slots;
+  const double h = 0.5 * a.dt;
+  const double* own = a.pos_cur + static_cast<int64_t>(a.own_shard) * 3 * S;
+  double* nown = a.pos_next + static_cast<int64_t>(a.own_shard) * 3 * S;
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+    const double v = __builtin_fma(h * a.kdk_acc[c * S + li], a.G, a.vel[c * S + li]);
+    a.vel[c * S + li] = v;
+    nown[c * S + li] = __builtin_fma(a.dt, v, own[c * S + li]);
   }
 }
 
@@ -527,14 +578,15 @@ void set_error(const char* fmt, ...) {
 
 using nbody_internal::set_error;
 
-int nbody_internal::tiny_run(const nbody_mi355x_step_args& a, int64_t substeps, hipStream_t stream) {
+int nbody_internal::tiny_run(const nbody_mi355x_step_args& a, int64_t substeps, bool kdk_prime, hipStream_t stream) {
   if (a.own_count < 1 || a.own_count > kTinyMaxBodies || a.num_shards != 1 || a.own_shard != 0 ||
       !a.pos_cur || !a.vel || !a.mass || a.shard_slots < a.own_count ||
-      substeps < 1 || !(a.eps2 >= 0.0)) {
+      substeps < 1 || !(a.eps2 >= 0.0) || a.integrator == NBODY_MI355X_KDK_CONTINUE ||
+      (a.integrator == NBODY_MI355X_KDK && !a.kdk_acc)) {
     set_error("tiny_run: not a one-slab system of at most %lld bodies", (long long)kTinyMaxBodies);
     return NBODY_MI355X_ERR_INVALID;
   }
-  hipLaunchKernelGGL(step_tiny_kernel, dim3(1), dim3(64), 0, stream, a, substeps);
+  hipLaunchKernelGGL(step_tiny_kernel, dim3(1), dim3(64), 0, stream, a, substeps, kdk_prime ? 1 : 0);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
     set_error("tiny_run launch: %s", hipGetErrorString(e));
@@ -590,11 +642,12 @@ int nbody_internal::check_step_args(const nbody_mi355x_step_args* a) {
       return NBODY_MI355X_ERR_INVALID;
     }
   }
-  if (a->acc_out == nullptr && (!a->pos_next || !a->vel)) {
+  const bool writes_pos = a->acc_out == nullptr && a->integrator != NBODY_MI355X_KDK;  // (KDK: second kick only)
+  if (a->acc_out == nullptr && (!a->vel || (writes_pos && !a->pos_next))) {
     set_error("step: integrating step needs pos_next and vel");
     return NBODY_MI355X_ERR_INVALID;
   }
-  if (a->pos_next == a->pos_cur && a->acc_out == nullptr) {
+  if (a->pos_next == a->pos_cur && writes_pos) {
     set_error("step: pos_next must not alias pos_cur");
     return NBODY_MI355X_ERR_INVALID;
   }
@@ -603,10 +656,29 @@ int nbody_internal::check_step_args(const nbody_mi355x_step_args* a) {
     set_error("step: unknown precision %d", a->precision);
     return NBODY_MI355X_ERR_INVALID;
   }
-  if (a->integrator != NBODY_MI355X_EULER && a->integrator != NBODY_MI355X_KICK_DRIFT) {
+  if (a->integrator < NBODY_MI355X_EULER || a->integrator > NBODY_MI355X_KDK_CONTINUE) {
     set_error("step: unknown integrator %d", a->integrator);
     return NBODY_MI355X_ERR_INVALID;
   }
+  return NBODY_MI355X_OK;
+}
+
+extern "C" int nbody_mi355x_kdk_drift_f64(const nbody_mi355x_step_args* a, void* stream) {
+  if (!a || !a->pos_cur || !a->pos_next || !a->vel || !a->kdk_acc || a->pos_next == a->pos_cur) {
+    set_error("kdk_drift: pos_cur, pos_next (distinct), vel and kdk_acc are required");
+    return NBODY_MI355X_ERR_INVALID;
+  }
+  if (a->shard_slots <= 0 || a->shard_slots % kTile != 0 || a->num_shards <= 0 || a->own_shard < 0 ||
+      a->own_shard >= a->num_shards || a->own_count < 0 || a->own_count > a->shard_slots) {
+    set_error("kdk_drift: bad slab layout (shard_slots=%lld, own_shard=%d of %d, own_count=%lld)",
+              (long long)a->shard_slots, a->own_shard, a->num_shards, (long long)a->own_count);
+    return NBODY_MI355X_ERR_INVALID;
+  }
+  if (a->own_count == 0) return NBODY_MI355X_OK;
+  hipLaunchKernelGGL(kdk_drift_kernel, dim3(static_cast<unsigned>((a->own_count + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), *a);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { set_error("kdk_drift launch: %s", hipGetErrorString(e)); return NBODY_MI355X_ERR_LAUNCH; }
   return NBODY_MI355X_OK;
 }
 

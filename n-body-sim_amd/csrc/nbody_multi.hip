@@ -39,6 +39,7 @@ struct Shard {
   double* mass = nullptr;               // [P][S]
   double* vel = nullptr;                // [3][S]   own bodies
   double* acc = nullptr;                // [3][S]   own bodies' complete sums
+  double* kacc = nullptr;               // [3][S]   KDK: the sums the last kick was made with
   double* acc_all = nullptr;            // [P][3][S] this shard's partial sums for every slot
   double* stage = nullptr;              // [P][3][S] the other shards' partial sums for the own slab
   double* snap = nullptr;               // [count][9] DeviceOutputParticle rows / [count][6] state rows
@@ -55,6 +56,7 @@ struct MultiSim {
   int P = 0;
   int cur = 0;
   bool sym = false;
+  bool kacc_valid = false;  // KDK: kacc holds the sums at the current positions
   int sym_variant = NBODY_MI355X_VARIANT_SYM;
   std::vector<Shard> sh;
   std::vector<double> host;  // slab-layout image for uploads
@@ -95,7 +97,7 @@ hipError_t pull(const Shard& to, void* dst, const Shard& from, const void* src, 
 void free_shard(Shard& s) {
   (void)hipSetDevice(s.device);
   if (s.stream) (void)hipStreamSynchronize(s.stream);
-  for (double** p : {&s.pos[0], &s.pos[1], &s.mass, &s.vel, &s.acc, &s.acc_all, &s.stage, &s.snap, &s.scratch}) {
+  for (double** p : {&s.pos[0], &s.pos[1], &s.mass, &s.vel, &s.acc, &s.kacc, &s.acc_all, &s.stage, &s.snap, &s.scratch}) {
     if (*p) (void)hipFree(*p);
     *p = nullptr;
   }
@@ -125,11 +127,33 @@ nbody_mi355x_step_args base_args(const MultiSim& m, const Shard& s, int r) {
   a.eps2 = m.cfg.eps2;
   a.precision = m.cfg.precision;
   a.integrator = m.cfg.integrator;
+  a.kdk_acc = s.kacc;
   return a;
 }
 
-// One small step of every shard, enqueued on the shards' streams.
-int multi_step(MultiSim& m, bool snapshot) {
+// "All-gather" by pulling: every shard fetches the other shards' slabs of pos[buf], each after
+// the owner's ev_pos.  q's pos[buf] was last read by q's own kernels, earlier on the same stream.
+int pull_positions(MultiSim& m, int buf) {
+  const int P = m.P;
+  const int64_t slab = 3 * m.S;
+  const size_t slab_bytes = sizeof(double) * static_cast<size_t>(slab);
+  for (int q = 0; q < P; q++) {
+    Shard& s = m.sh[q];
+    M_TRY(hipSetDevice(s.device), NBODY_MI355X_ERR_NO_DEVICE, "hipSetDevice");
+    for (int r = 0; r < P; r++) {
+      if (r == q) continue;
+      M_TRY(hipStreamWaitEvent(s.stream, m.sh[r].ev_pos, 0), NBODY_MI355X_ERR_LAUNCH, "wait positions");
+      M_TRY(pull(s, s.pos[buf] + r * slab, m.sh[r], m.sh[r].pos[buf] + r * slab, slab_bytes), NBODY_MI355X_ERR_LAUNCH,
+            "pull positions");
+    }
+  }
+  return NBODY_MI355X_OK;
+}
+
+// One small step of every shard, enqueued on the shards' streams.  integrator: the epilogue
+// (EULER / KICK_DRIFT / KDK_CONTINUE write new positions, which are then exchanged and become
+// current; KDK is the closing kick of a big step: velocities and sums only, nothing to exchange).
+int multi_step(MultiSim& m, bool snapshot, int integrator, double dt) {
   const int P = m.P;
   const int64_t S = m.S, slab = 3 * S;
   const size_t slab_bytes = sizeof(double) * static_cast<size_t>(slab);
@@ -141,6 +165,8 @@ int multi_step(MultiSim& m, bool snapshot) {
       Shard& s = m.sh[r];
       M_TRY(hipSetDevice(s.device), NBODY_MI355X_ERR_NO_DEVICE, "hipSetDevice");
       nbody_mi355x_step_args a = base_args(m, s, r);
+      a.integrator = integrator;
+      a.dt = dt;
       a.acc_out = s.acc_all;
       a.variant = m.sym_variant;
       a.workspace = s.workspace;
@@ -164,6 +190,8 @@ int multi_step(MultiSim& m, bool snapshot) {
                          s.stream, s.acc_all + r * slab, s.stage, P, r, slab, s.acc);
       M_TRY(hipGetLastError(), NBODY_MI355X_ERR_LAUNCH, "reduce launch");
       nbody_mi355x_step_args a = base_args(m, s, r);
+      a.integrator = integrator;
+      a.dt = dt;
       a.acc_in = s.acc;  // no j range: acc_in -> Euler update (+ snapshot)
       a.variant = 1;
       a.snapshot = snapshot ? s.snap : nullptr;
@@ -179,6 +207,8 @@ int multi_step(MultiSim& m, bool snapshot) {
       Shard& s = m.sh[r];
       M_TRY(hipSetDevice(s.device), NBODY_MI355X_ERR_NO_DEVICE, "hipSetDevice");
       nbody_mi355x_step_args a = base_args(m, s, r);
+      a.integrator = integrator;
+      a.dt = dt;
       a.j0_begin = 0;
       a.j0_end = static_cast<int64_t>(P) * S;
       a.variant = is_sym_variant(m.cfg.variant) ? 0 : m.cfg.variant;
@@ -188,18 +218,10 @@ int multi_step(MultiSim& m, bool snapshot) {
       M_TRY(hipEventRecord(s.ev_pos, s.stream), NBODY_MI355X_ERR_LAUNCH, "event record");
     }
   }
-  // C: "all-gather" by pulling the other shards' new slabs.  q's pos[next] was read by q's
-  //    own kernels of step k-1, earlier on the same stream.
-  for (int q = 0; q < P; q++) {
-    Shard& s = m.sh[q];
-    M_TRY(hipSetDevice(s.device), NBODY_MI355X_ERR_NO_DEVICE, "hipSetDevice");
-    for (int r = 0; r < P; r++) {
-      if (r == q) continue;
-      M_TRY(hipStreamWaitEvent(s.stream, m.sh[r].ev_pos, 0), NBODY_MI355X_ERR_LAUNCH, "wait positions");
-      M_TRY(pull(s, s.pos[nxt] + r * slab, m.sh[r], m.sh[r].pos[nxt] + r * slab, slab_bytes), NBODY_MI355X_ERR_LAUNCH,
-            "pull positions");
-    }
-  }
+  if (integrator == NBODY_MI355X_KDK) return NBODY_MI355X_OK;  // positions unchanged
+  // C: "all-gather" by pulling the other shards' new slabs
+  const int prc = pull_positions(m, nxt);
+  if (prc != NBODY_MI355X_OK) return prc;
   m.cur = nxt;
   return NBODY_MI355X_OK;
 }
@@ -287,6 +309,7 @@ int multi_create(const nbody_mi355x_config& cfg, const int32_t* devices, int32_t
          hipMalloc(&s.pos[1], all) == hipSuccess &&
          hipMalloc(&s.mass, sizeof(double) * static_cast<size_t>(S) * num) == hipSuccess &&
          hipMalloc(&s.vel, one) == hipSuccess && hipMalloc(&s.acc, one) == hipSuccess &&
+         (cfg.integrator != NBODY_MI355X_KDK || hipMalloc(&s.kacc, one) == hipSuccess) &&
          hipMalloc(&s.snap, sizeof(double) * 9 * static_cast<size_t>(s.count)) == hipSuccess &&
          hipMalloc(&s.scratch, sizeof(double) * static_cast<size_t>(2 * eblocks + 2)) == hipSuccess &&
          hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) == hipSuccess &&
@@ -359,6 +382,7 @@ int multi_upload(MultiSim* m, const double* particles, const double* mass) {
     M_TRY(hipStreamSynchronize(s.stream), NBODY_MI355X_ERR_H2D, "upload sync");  // hvel is reused
   }
   m->cur = 0;
+  m->kacc_valid = false;
   m->host.clear();
   m->host.shrink_to_fit();
   return NBODY_MI355X_OK;
@@ -370,9 +394,41 @@ int multi_enqueue(MultiSim* m, int64_t substeps, double* snapshot_out) {
     M_TRY(hipSetDevice(s.device), NBODY_MI355X_ERR_NO_DEVICE, "hipSetDevice");
     M_TRY(hipEventRecord(s.ev_t0, s.stream), NBODY_MI355X_ERR_LAUNCH, "event record");
   }
-  for (int64_t k = 0; k < substeps; k++) {
-    const int rc = multi_step(*m, snapshot_out != nullptr && k == substeps - 1);
-    if (rc != NBODY_MI355X_OK) return rc;
+  const double dt = m->cfg.stepsize;
+  if (m->cfg.integrator == NBODY_MI355X_KDK) {
+    // kick-drift-kick (see nbody_mi355x_run_async): sums carried in kacc (primed by a KDK step
+    // with dt = 0); drift + exchange; substeps-1 fused steps; the closing kick with the snapshot
+    if (!m->kacc_valid) {
+      const int rc = multi_step(*m, false, NBODY_MI355X_KDK, 0.0);
+      if (rc != NBODY_MI355X_OK) return rc;
+      m->kacc_valid = true;
+    }
+    const int nxt = m->cur ^ 1;
+    for (int r = 0; r < m->P; r++) {
+      Shard& s = m->sh[r];
+      M_TRY(hipSetDevice(s.device), NBODY_MI355X_ERR_NO_DEVICE, "hipSetDevice");
+      // r's slab of pos[nxt] was last read by its peers two exchanges ago; since then r has
+      // waited on an event each of them recorded after that read (ev_partials in B, or ev_pos
+      // in the exchange in between)
+      nbody_mi355x_step_args a = base_args(*m, s, r);
+      const int rc = nbody_mi355x_kdk_drift_f64(&a, s.stream);
+      if (rc != NBODY_MI355X_OK) return rc;
+      M_TRY(hipEventRecord(s.ev_pos, s.stream), NBODY_MI355X_ERR_LAUNCH, "event record");
+    }
+    const int prc = pull_positions(*m, nxt);
+    if (prc != NBODY_MI355X_OK) return prc;
+    m->cur = nxt;
+    for (int64_t k = 0; k + 1 < substeps; k++) {
+      const int rc = multi_step(*m, false, NBODY_MI355X_KDK_CONTINUE, dt);
+      if (rc != NBODY_MI355X_OK) { m->kacc_valid = false; return rc; }
+    }
+    const int rc = multi_step(*m, snapshot_out != nullptr, NBODY_MI355X_KDK, dt);
+    if (rc != NBODY_MI355X_OK) { m->kacc_valid = false; return rc; }
+  } else {
+    for (int64_t k = 0; k < substeps; k++) {
+      const int rc = multi_step(*m, snapshot_out != nullptr && k == substeps - 1, m->cfg.integrator, dt);
+      if (rc != NBODY_MI355X_OK) return rc;
+    }
   }
   for (Shard& s : m->sh) {
     M_TRY(hipSetDevice(s.device), NBODY_MI355X_ERR_NO_DEVICE, "hipSetDevice");

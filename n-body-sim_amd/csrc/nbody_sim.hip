@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -24,6 +25,8 @@ struct nbody_mi355x_sim {
   int64_t slots = 0;  // n rounded up to the tile
   double* pos[2] = {nullptr, nullptr};  // [3][slots] each
   double* vel = nullptr;                // [3][slots]
+  double* acc = nullptr;                // [3][slots]  KDK: the raw sums at the current positions
+  bool acc_valid = false;               //             ... once a step (or the priming call) has stored them
   double* mass = nullptr;               // [slots]
   double* aos = nullptr;                // staging: Particle<double>[n] / DeviceOutputParticle<double>[n]
   double* scratch = nullptr;            // energy partials + result
@@ -70,7 +73,7 @@ int free_all(nbody_mi355x_sim* s) {
     if (p && hipFree(p) != hipSuccess) rc = NBODY_MI355X_ERR_FREE;
     p = nullptr;
   };
-  fr(s->pos[0]); fr(s->pos[1]); fr(s->vel); fr(s->mass); fr(s->aos); fr(s->scratch);
+  fr(s->pos[0]); fr(s->pos[1]); fr(s->vel); fr(s->acc); fr(s->mass); fr(s->aos); fr(s->scratch);
   if (s->workspace && hipFree(s->workspace) != hipSuccess) rc = NBODY_MI355X_ERR_FREE;
   s->workspace = nullptr;
   for (auto& g : s->graph) {
@@ -94,7 +97,8 @@ static int check_config(const nbody_mi355x_config* cfg) {
     set_error("create: unknown precision %d", cfg->precision);
     return NBODY_MI355X_ERR_INVALID;
   }
-  if (cfg->integrator != NBODY_MI355X_EULER && cfg->integrator != NBODY_MI355X_KICK_DRIFT) {
+  if (cfg->integrator != NBODY_MI355X_EULER && cfg->integrator != NBODY_MI355X_KICK_DRIFT &&
+      cfg->integrator != NBODY_MI355X_KDK) {
     set_error("create: unknown integrator %d", cfg->integrator);
     return NBODY_MI355X_ERR_INVALID;
   }
@@ -149,6 +153,7 @@ extern "C" int nbody_mi355x_create(const nbody_mi355x_config* cfg, nbody_mi355x_
   const int64_t eblocks = s->slots / NBODY_MI355X_TILE;
   bool ok = hipMalloc(&s->pos[0], slab) == hipSuccess && hipMalloc(&s->pos[1], slab) == hipSuccess &&
             hipMalloc(&s->vel, slab) == hipSuccess &&
+            (cfg->integrator != NBODY_MI355X_KDK || hipMalloc(&s->acc, slab) == hipSuccess) &&
             hipMalloc(&s->mass, sizeof(double) * static_cast<size_t>(s->slots)) == hipSuccess &&
             hipMalloc(&s->aos, sizeof(double) * 9 * static_cast<size_t>(s->n)) == hipSuccess &&
             hipMalloc(&s->scratch, sizeof(double) * static_cast<size_t>(2 * eblocks + 2)) == hipSuccess &&
@@ -233,6 +238,7 @@ extern "C" int nbody_mi355x_upload(nbody_mi355x_sim* s, const void* particles, c
   HIP_TRY(hipMemcpyAsync(s->mass, hm, sizeof(double) * n, hipMemcpyHostToDevice, s->stream),
           NBODY_MI355X_ERR_H2D, "copy masses");
   s->cur = 0;
+  s->acc_valid = false;
   int rc = nbody_mi355x_pack_f64(s->aos, s->n, s->pos[0], s->vel, s->slots, s->stream);
   if (rc != NBODY_MI355X_OK) return rc;
   HIP_TRY(hipStreamSynchronize(s->stream), NBODY_MI355X_ERR_H2D, "upload sync");
@@ -301,6 +307,7 @@ static nbody_mi355x_step_args step_args_of(const nbody_mi355x_sim* s) {
   a.precision = s->cfg.precision;
   a.variant = s->cfg.variant;
   a.integrator = s->cfg.integrator;
+  a.kdk_acc = s->acc;
   a.workspace = s->workspace;
   a.workspace_bytes = s->workspace_bytes;
   return a;
@@ -342,30 +349,56 @@ extern "C" int nbody_mi355x_run_async(nbody_mi355x_sim* s, int64_t substeps, voi
   int64_t k = 0;
   // at most 64 bodies: the whole big step is ONE launch of one wave (tiny_run), in place on
   // pos[cur] -- the reference's two- and eight-body scenes take 324 000 small steps per big step
+  const bool kdk = s->cfg.integrator == NBODY_MI355X_KDK;
+  int rc = NBODY_MI355X_OK;
   if (takes_tiny_path(s)) {
     a.pos_cur = s->pos[s->cur];
     a.pos_next = nullptr;
     a.snapshot = snapshot_out ? s->aos : nullptr;
-    const int rc = nbody_internal::tiny_run(a, substeps, s->stream);
-    if (rc != NBODY_MI355X_OK) return rc;
-    k = substeps;
+    rc = nbody_internal::tiny_run(a, substeps, kdk && !s->acc_valid, s->stream);
+    if (rc == NBODY_MI355X_OK) {
+      k = substeps;
+      s->acc_valid = kdk;
+    }
   }
-  const int64_t replayable = substeps - (snapshot_out ? 1 : 0);  // the snapshot step is launched plainly
-  if (k == 0 && s->n <= kGraphMaxBodies && replayable >= 2 * kGraphSteps && !s->graph_failed) {
+  // kick-drift-kick (not in the reference): the sums at the current positions are carried from
+  // big step to big step in s->acc -- one extra evaluation (a KDK call with dt = 0) the first
+  // time -- so that a big step is: drift; substeps-1 x {forces, kick, kick, drift} in one
+  // epilogue; {forces, kick} with the snapshot.  The state between big steps is synchronised.
+  if (rc == NBODY_MI355X_OK && kdk && k == 0) {
+    if (!s->acc_valid) {
+      nbody_mi355x_step_args prime = a;
+      prime.dt = 0.0;
+      prime.pos_cur = s->pos[s->cur];
+      prime.pos_next = nullptr;
+      rc = nbody_mi355x_step_f64(&prime, s->stream);
+      s->acc_valid = rc == NBODY_MI355X_OK;
+    }
+    if (rc == NBODY_MI355X_OK) {
+      a.pos_cur = s->pos[s->cur];
+      a.pos_next = s->pos[s->cur ^ 1];
+      rc = nbody_mi355x_kdk_drift_f64(&a, s->stream);
+      if (rc == NBODY_MI355X_OK) s->cur ^= 1;
+    }
+    a.integrator = NBODY_MI355X_KDK_CONTINUE;  // every small step but the last
+  }
+  // the snapshot step, and the last step of a KDK big step, are launched plainly
+  const int64_t replayable = substeps - ((snapshot_out || kdk) ? 1 : 0);
+  if (rc == NBODY_MI355X_OK && k == 0 && s->n <= kGraphMaxBodies && replayable >= 2 * kGraphSteps && !s->graph_failed) {
     hipGraphExec_t& exec = s->graph[s->cur];
     if (!exec) {
       hipGraph_t graph = nullptr;
       bool ok = hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
-      int rc = NBODY_MI355X_OK;
+      int crc = NBODY_MI355X_OK;
       if (ok) {
         a.snapshot = nullptr;
         int c = s->cur;
-        for (int g = 0; g < kGraphSteps && rc == NBODY_MI355X_OK; g++, c ^= 1) {
+        for (int g = 0; g < kGraphSteps && crc == NBODY_MI355X_OK; g++, c ^= 1) {
           a.pos_cur = s->pos[c];
           a.pos_next = s->pos[c ^ 1];
-          rc = nbody_mi355x_step_f64(&a, s->stream);
+          crc = nbody_mi355x_step_f64(&a, s->stream);
         }
-        ok = hipStreamEndCapture(s->stream, &graph) == hipSuccess && rc == NBODY_MI355X_OK && graph != nullptr;
+        ok = hipStreamEndCapture(s->stream, &graph) == hipSuccess && crc == NBODY_MI355X_OK && graph != nullptr;
       }
       if (ok) ok = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess;
       if (graph) (void)hipGraphDestroy(graph);
@@ -376,17 +409,39 @@ extern "C" int nbody_mi355x_run_async(nbody_mi355x_sim* s, int64_t substeps, voi
       }
     }
     while (exec && k + kGraphSteps <= replayable) {
-      HIP_TRY(hipGraphLaunch(exec, s->stream), NBODY_MI355X_ERR_LAUNCH, "graph launch");
+      if (hipGraphLaunch(exec, s->stream) != hipSuccess) {
+        (void)hipGetLastError();
+        set_error("graph launch failed");
+        rc = NBODY_MI355X_ERR_LAUNCH;
+        break;
+      }
       k += kGraphSteps;  // an even number of steps: s->cur is unchanged
     }
   }
-  for (; k < substeps; k++) {
+  for (; rc == NBODY_MI355X_OK && k < substeps; k++) {
+    const bool last = k == substeps - 1;
     a.pos_cur = s->pos[s->cur];
     a.pos_next = s->pos[s->cur ^ 1];
-    a.snapshot = (snapshot_out && k == substeps - 1) ? s->aos : nullptr;
-    int rc = nbody_mi355x_step_f64(&a, s->stream);
-    if (rc != NBODY_MI355X_OK) return rc;
-    s->cur ^= 1;  // ref: pointer swap after every small step, .cu:157-162
+    a.snapshot = (snapshot_out && last) ? s->aos : nullptr;
+    if (kdk) a.integrator = last ? NBODY_MI355X_KDK : NBODY_MI355X_KDK_CONTINUE;
+    rc = nbody_mi355x_step_f64(&a, s->stream);
+    if (rc != NBODY_MI355X_OK) break;
+    if (!(kdk && last)) s->cur ^= 1;  // ref: pointer swap after every small step, .cu:157-162
+  }
+  if (rc != NBODY_MI355X_OK) {
+    // a launch failed with part of the big step enqueued: leave the handle consistent -- the
+    // work in flight is marked pending so that wait() (or the caller's next call) drains it,
+    // no snapshot is delivered, and the KDK carry-over is recomputed next time
+    const char* text = nbody_mi355x_last_error();
+    char keep[512];
+    snprintf(keep, sizeof keep, "%s", text ? text : "");
+    (void)hipEventRecord(s->ev1, s->stream);
+    s->pending = true;
+    s->pending_out = nullptr;
+    s->acc_valid = false;
+    (void)nbody_mi355x_wait(s);
+    set_error("%s", keep);
+    return rc;
   }
   HIP_TRY(hipEventRecord(s->ev1, s->stream), NBODY_MI355X_ERR_LAUNCH, "event record");
   if (snapshot_out) {

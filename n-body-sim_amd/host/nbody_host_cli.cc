@@ -126,6 +126,7 @@ std::string Simulate(ParticleSimulation<T, W>& sim, const std::string& path) {
   if (path == "avx512" || path == "avx512-f32") return sim.SimulateAVX512() ? "ok" : "no AVX-512F on this CPU";
   if (path == "mi355x" || path == "mi355x-f32host") return sim.SimulateMI355X();
   if (path == "mi355x-fp32") return sim.SimulateMI355X(0, true);
+  if (path == "mi355x-kdk") return sim.SimulateMI355X(0, false, 0, NBODY_MI355X_KDK);
   if (path.rfind("mi355x-shards", 0) == 0) {  // mi355x-shardsK: K shards, round-robin over the visible GPUs
     const int k = std::atoi(path.c_str() + 13);
     int ndev = 0;

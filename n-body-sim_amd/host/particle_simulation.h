@@ -7,7 +7,7 @@
 // compiles against this header unchanged; the one new member is
 //
 //     std::string SimulateMI355X(int device = 0, bool fp32_forces = false,
-//                                float_t softening_squared = 0, bool kick_drift = false);
+//                                float_t softening_squared = 0, int integrator = NBODY_MI355X_EULER);
 //     std::string SimulateMI355X(const std::vector<int>& devices, ...same options...);
 //
 // the sibling of the reference's SimulateGPU(int blocksize) (ref: particle_simulation.h:559,
@@ -357,18 +357,19 @@ class ParticleSimulation {
   // a = 0, t = 0; out_put_data_[k] = state after big step k with a = G*sum, m, and
   // t = stepsize * substeps * k (ref: .cu:239-266); execution_time_ per big step;
   // progress print per big step; a "Device execution time" line; a status string.
-  // kick_drift = true swaps the reference's forward Euler for the symplectic kick-drift
-  // step (same cost); the default reproduces the reference.
+  // integrator: NBODY_MI355X_EULER (the default: the reference's forward Euler),
+  // NBODY_MI355X_KICK_DRIFT (symplectic Euler, same cost) or NBODY_MI355X_KDK (kick-drift-kick
+  // leapfrog, second order, still one force evaluation per small step).
   std::string SimulateMI355X(int device = 0, bool fp32_forces = false, float_t softening_squared = 0,
-                             bool kick_drift = false) {
-    return SimulateMI355X(std::vector<int>{device}, fp32_forces, softening_squared, kick_drift);
+                             int integrator = NBODY_MI355X_EULER) {
+    return SimulateMI355X(std::vector<int>{device}, fp32_forces, softening_squared, integrator);
   }
 
   // The same over several GPUs driven by this one host thread: devices[k] owns the k-th
   // contiguous i-range of bodies, the partition of the CPU paths' threads (ref:
   // particle_simulation.h:98-110).  An ordinal may repeat (several shards on one GPU).
   std::string SimulateMI355X(const std::vector<int>& devices, bool fp32_forces = false,
-                             float_t softening_squared = 0, bool kick_drift = false) {
+                             float_t softening_squared = 0, int integrator = NBODY_MI355X_EULER) {
     IntervallTimer device_execution_timer;
     nbody_mi355x_config cfg{};
     cfg.num_particles = num_particles_;
@@ -378,7 +379,7 @@ class ParticleSimulation {
     cfg.precision = fp32_forces ? NBODY_MI355X_FP32 : NBODY_MI355X_FP64;
     cfg.device = devices.empty() ? 0 : devices[0];
     cfg.host_is_float = std::is_same<float_t, float>::value ? 1 : 0;
-    cfg.integrator = kick_drift ? NBODY_MI355X_KICK_DRIFT : NBODY_MI355X_EULER;
+    cfg.integrator = integrator;
     nbody_mi355x_sim* sim = nullptr;
     const std::vector<int32_t> devs(devices.begin(), devices.end());
     int rc = devs.size() > 1 ? nbody_mi355x_create_multi(&cfg, devs.data(), static_cast<int32_t>(devs.size()), &sim)

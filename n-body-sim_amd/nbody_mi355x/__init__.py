@@ -24,7 +24,7 @@ LIB_PATH = ROOT / "lib" / "libnbody_mi355x.so"
 TILE = 256
 G_REFERENCE = 6.7430e-11  # reference: particle_simulation.h:713
 FP64, FP32 = 0, 1
-EULER, KICK_DRIFT = 0, 1
+EULER, KICK_DRIFT, KDK, KDK_CONTINUE = 0, 1, 2, 3   # KDK_CONTINUE: level 1 (StepArgs) only
 
 OK = 0
 ERR_INVALID, ERR_ALLOC, ERR_H2D, ERR_D2H, ERR_FREE, ERR_LAUNCH, ERR_NO_DEVICE = range(-1, -8, -1)
@@ -49,6 +49,7 @@ class StepArgs(C.Structure):
         ("precision", C.c_int32), ("variant", C.c_int32),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
         ("phase", C.c_int32), ("integrator", C.c_int32),
+        ("kdk_acc", C.c_void_p),
     ]
 
 
@@ -78,6 +79,7 @@ SYMBOLS = {
     "nbody_mi355x_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "nbody_mi355x_step_f64": (C.c_int, [C.POINTER(StepArgs), _P]),
     "nbody_mi355x_step_f64_static": (C.c_int, [C.POINTER(StepArgs), _P]),
+    "nbody_mi355x_kdk_drift_f64": (C.c_int, [C.POINTER(StepArgs), _P]),
     "nbody_mi355x_step_variant": (C.c_int, [C.POINTER(StepArgs), C.POINTER(C.c_int32)]),
     "nbody_mi355x_step_workspace_bytes": (C.c_int, [C.POINTER(StepArgs), C.POINTER(C.c_int64)]),
     "nbody_mi355x_pack_f64": (C.c_int, [_P, C.c_int64, _P, _P, C.c_int64, _P]),

@@ -26,8 +26,8 @@ def test_header_symbols_all_exported_and_bound():
 
 def test_struct_sizes_match_header_layout():
     import ctypes as C
-    # 7 pointers + int64 + 2 int32 + 5 int64 + 3 double + 2 int32 + pointer + int64 + 2 int32
-    assert C.sizeof(nb.StepArgs) == 7 * 8 + 8 + 8 + 5 * 8 + 3 * 8 + 8 + 16 + 8
+    # 7 pointers + int64 + 2 int32 + 5 int64 + 3 double + 2 int32 + pointer + int64 + 2 int32 + pointer
+    assert C.sizeof(nb.StepArgs) == 7 * 8 + 8 + 8 + 5 * 8 + 3 * 8 + 8 + 16 + 8 + 8
     assert C.sizeof(nb.Config) == 8 + 3 * 8 + 6 * 4
 
 
@@ -120,6 +120,9 @@ def test_python_constants_mirror_the_header():
     assert int(defs["VARIANT_WAVE"]) == nb.VARIANT_WAVE and int(defs["VARIANT_TINY"]) == nb.VARIANT_TINY
     assert int(defs["VARIANT_SYM"]) == nb.VARIANT_SYM and int(defs["VARIANT_SYM8"]) == nb.VARIANT_SYM8
     assert int(defs["TILE"]) == nb.TILE and float(defs["G_REFERENCE"]) == nb.G_REFERENCE
+    assert [int(defs[k]) for k in ("EULER", "KICK_DRIFT", "KDK", "KDK_CONTINUE")] == [nb.EULER, nb.KICK_DRIFT, nb.KDK, nb.KDK_CONTINUE]
+    assert [int(defs[f"VARIANT_SYMW{k}"]) for k in (1, 2, 4, 8)] == [nb.VARIANT_SYMW1, nb.VARIANT_SYMW2, nb.VARIANT_SYMW4, nb.VARIANT_SYMW8]
+    assert int(defs["STATIC_SCRATCH_BYTES"]) == nb.STATIC_SCRATCH_BYTES
 
 
 def test_step_variant_reports_the_kernel_choice_without_a_gpu():
