@@ -3,25 +3,37 @@
 // (particle_simulation_GPU.cu:13-35); the partition is the one of its CPU threads
 // (particle_simulation.h:98-110): shard k owns the k-th contiguous i-range, remainder to the
 // low shards.  The Python driver (nbody_mi355x/sharded.py) is the same scheme with one
-// process per GPU and RCCL; here the two exchanges of a small step are peer copies between
-// the shards' streams, ordered by events, and nothing blocks the host inside a big step:
+// process per GPU and RCCL through torch.distributed; here every shard has a COMPUTE stream
+// and a COMM stream, nothing blocks the host inside a big step, and a small step is
 //
 //   pair-symmetric path (large systems):
-//     A  every shard: tiles of its block rows -> partial sums for EVERY slot (acc_all)
-//     B  every shard: pulls the other shards' partial sums for ITS slab, adds them in shard
-//        order (deterministic), integrates its bodies into its slab of pos[next]
-//     C  every shard: pulls the other shards' new slabs into its pos[next]
-//   one-sided path (small systems, or no room for the workspace): A+B are one step call.
+//     A1 compute: the tiles that need only the own slab (phase 1, the diagonal) -- while the
+//        comm stream is still fetching the other shards' positions of the previous step
+//     A2 compute: waits for that exchange, then all other tiles -> partial sums for EVERY
+//        slot (acc_all)
+//     B  compute: "reduce-scatter" -- pulls the other shards' partial sums for ITS slab, adds
+//        them in shard order (deterministic), integrates its bodies into its slab of pos[next]
+//     C  comm:    "all-gather" -- pulls the other shards' new slabs into its pos[next]
+//   one-sided path (small systems, or no room for the workspace): A+B are one step call
+//   after the exchange.
 //
-// Ordering argument (why no extra events are needed): a buffer that a peer reads in step k
-// is next written by its owner only after the owner has waited, in step k+1, on an event
-// that every peer records AFTER its step-k reads, in stream order (see multi_step).
-// A device ordinal may appear more than once: several shards on one GPU, which is how this
-// path is tested on a one-GPU machine (tests/test_gpu_multi.py).
+// The two exchanges are peer copies ordered by events by default.  With
+// NBODY_MI355X_MULTI_RCCL=1 and all shards on distinct GPUs they are ncclReduceScatter and an
+// in-place ncclAllGather of one communicator over the listed devices (ncclCommInitAll), the
+// library resolved at run time from the process (torch's copy if one is mapped) or
+// /opt/rocm/lib -- no link-time dependency.  That path has only been run with a one-rank
+// communicator (a one-GPU box cannot do more): it is opt-in until it has run on a multi-GPU
+// node, and its sums are added in RCCL's order, not shard order.
+//
+// Ordering argument: see multi_step and gather_positions.  A device ordinal may appear more
+// than once: several shards on one GPU, which is how this path is tested on a one-GPU machine
+// (tests/test_gpu_multi.py).
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -46,9 +58,24 @@ struct Shard {
   double* scratch = nullptr;            // energy partials + result
   void* workspace = nullptr;
   int64_t workspace_bytes = 0;
-  hipStream_t stream = nullptr;
-  hipEvent_t ev_partials = nullptr, ev_pos = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
+  hipStream_t stream = nullptr;  // compute
+  hipStream_t comm = nullptr;    // the exchange of positions
+  hipEvent_t ev_partials = nullptr, ev_pos = nullptr, ev_gathered = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
+  void* nccl = nullptr;          // ncclComm_t of this shard (RCCL path only)
 };
+
+// RCCL, resolved at run time (no link-time dependency; see the file header)
+struct Rccl {
+  void* lib = nullptr;
+  int (*CommInitAll)(void**, int, const int*) = nullptr;
+  int (*CommDestroy)(void*) = nullptr;
+  int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+  int (*ReduceScatter)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+};
+constexpr int kNcclDouble = 8, kNcclSum = 0;  // rccl.h: ncclFloat64 = 8, ncclSum = 0
 
 struct MultiSim {
   nbody_mi355x_config cfg{};
@@ -57,6 +84,8 @@ struct MultiSim {
   int cur = 0;
   bool sym = false;
   bool kacc_valid = false;  // KDK: kacc holds the sums at the current positions
+  bool rccl = false;        // the exchanges are RCCL collectives (opt-in), else peer copies
+  Rccl nccl;
   int sym_variant = NBODY_MI355X_VARIANT_SYM;
   std::vector<Shard> sh;
   std::vector<double> host;  // slab-layout image for uploads
@@ -88,27 +117,56 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const double* __re
   out[i] = s;
 }
 
-// dst (on shard `to`) <- src (on shard `from`), on `to`'s stream
-hipError_t pull(const Shard& to, void* dst, const Shard& from, const void* src, size_t bytes) {
-  if (to.device == from.device) return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, to.stream);
-  return hipMemcpyPeerAsync(dst, to.device, src, from.device, bytes, to.stream);
+// dst (on shard `to`) <- src (on shard `from`), on a stream of `to`
+hipError_t pull(const Shard& to, hipStream_t stream, void* dst, const Shard& from, const void* src, size_t bytes) {
+  if (to.device == from.device) return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, stream);
+  return hipMemcpyPeerAsync(dst, to.device, src, from.device, bytes, stream);
+}
+
+#define NCCL_TRY(m, expr, what)                                                          \
+  do {                                                                                   \
+    const int r_ = (expr);                                                               \
+    if (r_ != 0) {                                                                       \
+      set_error("multi: %s: %s", what, (m).nccl.GetErrorString ? (m).nccl.GetErrorString(r_) : "RCCL error"); \
+      return NBODY_MI355X_ERR_LAUNCH;                                                    \
+    }                                                                                    \
+  } while (0)
+
+bool load_rccl(Rccl* r) {
+  // a copy already mapped into the process (torch ships its own) wins: one RCCL, one HIP runtime
+  void* lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
+  if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD);
+  if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW);
+  if (!lib) lib = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW);
+  if (!lib) return false;
+  r->lib = lib;
+  r->CommInitAll = reinterpret_cast<decltype(r->CommInitAll)>(dlsym(lib, "ncclCommInitAll"));
+  r->CommDestroy = reinterpret_cast<decltype(r->CommDestroy)>(dlsym(lib, "ncclCommDestroy"));
+  r->AllGather = reinterpret_cast<decltype(r->AllGather)>(dlsym(lib, "ncclAllGather"));
+  r->ReduceScatter = reinterpret_cast<decltype(r->ReduceScatter)>(dlsym(lib, "ncclReduceScatter"));
+  r->GroupStart = reinterpret_cast<decltype(r->GroupStart)>(dlsym(lib, "ncclGroupStart"));
+  r->GroupEnd = reinterpret_cast<decltype(r->GroupEnd)>(dlsym(lib, "ncclGroupEnd"));
+  r->GetErrorString = reinterpret_cast<decltype(r->GetErrorString)>(dlsym(lib, "ncclGetErrorString"));
+  return r->CommInitAll && r->CommDestroy && r->AllGather && r->ReduceScatter && r->GroupStart && r->GroupEnd;
 }
 
 void free_shard(Shard& s) {
   (void)hipSetDevice(s.device);
   if (s.stream) (void)hipStreamSynchronize(s.stream);
+  if (s.comm) (void)hipStreamSynchronize(s.comm);
   for (double** p : {&s.pos[0], &s.pos[1], &s.mass, &s.vel, &s.acc, &s.kacc, &s.acc_all, &s.stage, &s.snap, &s.scratch}) {
     if (*p) (void)hipFree(*p);
     *p = nullptr;
   }
   if (s.workspace) (void)hipFree(s.workspace);
   s.workspace = nullptr;
-  for (hipEvent_t* e : {&s.ev_partials, &s.ev_pos, &s.ev_t0, &s.ev_t1}) {
+  for (hipEvent_t* e : {&s.ev_partials, &s.ev_pos, &s.ev_gathered, &s.ev_t0, &s.ev_t1}) {
     if (*e) (void)hipEventDestroy(*e);
     *e = nullptr;
   }
   if (s.stream) (void)hipStreamDestroy(s.stream);
-  s.stream = nullptr;
+  if (s.comm) (void)hipStreamDestroy(s.comm);
+  s.stream = s.comm = nullptr;
 }
 
 nbody_mi355x_step_args base_args(const MultiSim& m, const Shard& s, int r) {
@@ -131,20 +189,42 @@ nbody_mi355x_step_args base_args(const MultiSim& m, const Shard& s, int r) {
   return a;
 }
 
-// "All-gather" by pulling: every shard fetches the other shards' slabs of pos[buf], each after
-// the owner's ev_pos.  q's pos[buf] was last read by q's own kernels, earlier on the same stream.
-int pull_positions(MultiSim& m, int buf) {
+// The exchange of positions ("all-gather"), on every shard's COMM stream: shard q fetches the
+// other shards' slabs of pos[buf], each after its owner's ev_pos, and records ev_gathered.
+// What it overwrites -- q's copies of the other slabs -- was last read by q's own kernels one
+// step ago, before q's ev_pos of this step in stream order: the comm stream waits for that too.
+// What it reads -- r's own slab of pos[buf] -- is next written by r two steps on, after r has
+// waited (in B, or in the one-sided kernel's place in the stream) on events q records after
+// ev_gathered.
+int gather_positions(MultiSim& m, int buf) {
   const int P = m.P;
   const int64_t slab = 3 * m.S;
   const size_t slab_bytes = sizeof(double) * static_cast<size_t>(slab);
   for (int q = 0; q < P; q++) {
     Shard& s = m.sh[q];
     M_TRY(hipSetDevice(s.device), NBODY_MI355X_ERR_NO_DEVICE, "hipSetDevice");
+    M_TRY(hipStreamWaitEvent(s.comm, s.ev_pos, 0), NBODY_MI355X_ERR_LAUNCH, "wait own positions");
+    if (m.rccl) continue;
     for (int r = 0; r < P; r++) {
       if (r == q) continue;
-      M_TRY(hipStreamWaitEvent(s.stream, m.sh[r].ev_pos, 0), NBODY_MI355X_ERR_LAUNCH, "wait positions");
-      M_TRY(pull(s, s.pos[buf] + r * slab, m.sh[r], m.sh[r].pos[buf] + r * slab, slab_bytes), NBODY_MI355X_ERR_LAUNCH,
-            "pull positions");
+      M_TRY(hipStreamWaitEvent(s.comm, m.sh[r].ev_pos, 0), NBODY_MI355X_ERR_LAUNCH, "wait positions");
+      M_TRY(pull(s, s.comm, s.pos[buf] + r * slab, m.sh[r], m.sh[r].pos[buf] + r * slab, slab_bytes),
+            NBODY_MI355X_ERR_LAUNCH, "pull positions");
+    }
+    M_TRY(hipEventRecord(s.ev_gathered, s.comm), NBODY_MI355X_ERR_LAUNCH, "event record");
+  }
+  if (m.rccl) {  // one in-place all-gather: every shard's own slab into its place everywhere
+    NCCL_TRY(m, m.nccl.GroupStart(), "ncclGroupStart");
+    for (int q = 0; q < P; q++) {
+      Shard& s = m.sh[q];
+      NCCL_TRY(m, m.nccl.AllGather(s.pos[buf] + q * slab, s.pos[buf], static_cast<size_t>(slab), kNcclDouble, s.nccl, s.comm),
+               "ncclAllGather");
+    }
+    NCCL_TRY(m, m.nccl.GroupEnd(), "ncclGroupEnd");
+    for (int q = 0; q < P; q++) {
+      Shard& s = m.sh[q];
+      M_TRY(hipSetDevice(s.device), NBODY_MI355X_ERR_NO_DEVICE, "hipSetDevice");
+      M_TRY(hipEventRecord(s.ev_gathered, s.comm), NBODY_MI355X_ERR_LAUNCH, "event record");
     }
   }
   return NBODY_MI355X_OK;
@@ -159,40 +239,68 @@ int multi_step(MultiSim& m, bool snapshot, int integrator, double dt) {
   const size_t slab_bytes = sizeof(double) * static_cast<size_t>(slab);
   const int nxt = m.cur ^ 1;
   if (m.sym) {
-    // A: partial sums.  acc_all of shard r was last read by its peers in step k-1 (B); r got
-    //    past C of step k-1 only after every peer's ev_pos of step k-1, recorded after those reads.
+    // A1: the diagonal tiles need the own slab only, which the shard wrote itself: they run
+    //     while the comm stream is still fetching the other slabs of pos[cur].  (Their sums
+    //     stay in the workspace; the workspace's previous contents were consumed by the
+    //     gather kernel of the last step's A2, earlier on this stream.)
     for (int r = 0; r < P; r++) {
       Shard& s = m.sh[r];
       M_TRY(hipSetDevice(s.device), NBODY_MI355X_ERR_NO_DEVICE, "hipSetDevice");
       nbody_mi355x_step_args a = base_args(m, s, r);
-      a.integrator = integrator;
-      a.dt = dt;
+      a.variant = m.sym_variant;
+      a.workspace = s.workspace;
+      a.workspace_bytes = s.workspace_bytes;
+      a.phase = 1;
+      const int rc = nbody_mi355x_step_f64(&a, s.stream);
+      if (rc != NBODY_MI355X_OK) return rc;
+    }
+    // A2: everything else, once the exchange is complete.  acc_all of shard r was last read by
+    //     its peers in B of the previous step; r's wait on ev_gathered is a wait on every
+    //     peer's ev_pos of that step, recorded after those reads.
+    for (int r = 0; r < P; r++) {
+      Shard& s = m.sh[r];
+      M_TRY(hipSetDevice(s.device), NBODY_MI355X_ERR_NO_DEVICE, "hipSetDevice");
+      M_TRY(hipStreamWaitEvent(s.stream, s.ev_gathered, 0), NBODY_MI355X_ERR_LAUNCH, "wait exchange");
+      nbody_mi355x_step_args a = base_args(m, s, r);
       a.acc_out = s.acc_all;
       a.variant = m.sym_variant;
       a.workspace = s.workspace;
       a.workspace_bytes = s.workspace_bytes;
+      a.phase = 2;
       const int rc = nbody_mi355x_step_f64(&a, s.stream);
       if (rc != NBODY_MI355X_OK) return rc;
       M_TRY(hipEventRecord(s.ev_partials, s.stream), NBODY_MI355X_ERR_LAUNCH, "event record");
     }
-    // B: "reduce-scatter" by pulling, then integrate.  r's slab of pos[next] was last read by
-    //    its peers in C of step k-2; each peer recorded ev_partials (waited on here) after that.
+    // B: "reduce-scatter", then integrate.  r's slab of pos[next] was last read by its peers
+    //    in C two steps ago; each peer recorded ev_partials (waited on here) after its wait on
+    //    the ev_gathered that closed that read.
+    if (m.rccl) {
+      NCCL_TRY(m, m.nccl.GroupStart(), "ncclGroupStart");
+      for (int r = 0; r < P; r++) {
+        Shard& s = m.sh[r];
+        NCCL_TRY(m, m.nccl.ReduceScatter(s.acc_all, s.acc, static_cast<size_t>(slab), kNcclDouble, kNcclSum, s.nccl, s.stream),
+                 "ncclReduceScatter");
+      }
+      NCCL_TRY(m, m.nccl.GroupEnd(), "ncclGroupEnd");
+    }
     for (int r = 0; r < P; r++) {
       Shard& s = m.sh[r];
       M_TRY(hipSetDevice(s.device), NBODY_MI355X_ERR_NO_DEVICE, "hipSetDevice");
-      for (int q = 0; q < P; q++) {
-        if (q == r) continue;
-        M_TRY(hipStreamWaitEvent(s.stream, m.sh[q].ev_partials, 0), NBODY_MI355X_ERR_LAUNCH, "wait partials");
-        M_TRY(pull(s, s.stage + q * slab, m.sh[q], m.sh[q].acc_all + r * slab, slab_bytes), NBODY_MI355X_ERR_LAUNCH,
-              "pull partial sums");
+      if (!m.rccl) {
+        for (int q = 0; q < P; q++) {
+          if (q == r) continue;
+          M_TRY(hipStreamWaitEvent(s.stream, m.sh[q].ev_partials, 0), NBODY_MI355X_ERR_LAUNCH, "wait partials");
+          M_TRY(pull(s, s.stream, s.stage + q * slab, m.sh[q], m.sh[q].acc_all + r * slab, slab_bytes),
+                NBODY_MI355X_ERR_LAUNCH, "pull partial sums");
+        }
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3(static_cast<unsigned>((slab + 255) / 256)), dim3(256), 0,
+                           s.stream, s.acc_all + r * slab, s.stage, P, r, slab, s.acc);
+        M_TRY(hipGetLastError(), NBODY_MI355X_ERR_LAUNCH, "reduce launch");
       }
-      hipLaunchKernelGGL(reduce_partials_kernel, dim3(static_cast<unsigned>((slab + 255) / 256)), dim3(256), 0,
-                         s.stream, s.acc_all + r * slab, s.stage, P, r, slab, s.acc);
-      M_TRY(hipGetLastError(), NBODY_MI355X_ERR_LAUNCH, "reduce launch");
       nbody_mi355x_step_args a = base_args(m, s, r);
       a.integrator = integrator;
       a.dt = dt;
-      a.acc_in = s.acc;  // no j range: acc_in -> Euler update (+ snapshot)
+      a.acc_in = s.acc;  // no j range: acc_in -> the integrator's update (+ snapshot)
       a.variant = 1;
       a.snapshot = snapshot ? s.snap : nullptr;
       const int rc = nbody_mi355x_step_f64(&a, s.stream);
@@ -200,12 +308,14 @@ int multi_step(MultiSim& m, bool snapshot, int integrator, double dt) {
       M_TRY(hipEventRecord(s.ev_pos, s.stream), NBODY_MI355X_ERR_LAUNCH, "event record");
     }
   } else {
-    // one-sided: every shard sums over all slabs and integrates in one call.  r's slab of
-    // pos[next] was last read by its peers in C of step k-2; r's C of step k-1 waited on their
-    // ev_pos of step k-1, recorded after those reads.
+    // one-sided: every shard sums over all slabs and integrates in one call, after the
+    // exchange.  r's slab of pos[next] was last read by its peers in C two steps ago; r's wait
+    // on ev_gathered of the step in between was a wait on ev_pos events its peers recorded
+    // after their own waits on the ev_gathered that closed that read.
     for (int r = 0; r < P; r++) {
       Shard& s = m.sh[r];
       M_TRY(hipSetDevice(s.device), NBODY_MI355X_ERR_NO_DEVICE, "hipSetDevice");
+      M_TRY(hipStreamWaitEvent(s.stream, s.ev_gathered, 0), NBODY_MI355X_ERR_LAUNCH, "wait exchange");
       nbody_mi355x_step_args a = base_args(m, s, r);
       a.integrator = integrator;
       a.dt = dt;
@@ -219,8 +329,8 @@ int multi_step(MultiSim& m, bool snapshot, int integrator, double dt) {
     }
   }
   if (integrator == NBODY_MI355X_KDK) return NBODY_MI355X_OK;  // positions unchanged
-  // C: "all-gather" by pulling the other shards' new slabs
-  const int prc = pull_positions(m, nxt);
+  // C: the exchange of the new positions, on the comm streams
+  const int prc = gather_positions(m, nxt);
   if (prc != NBODY_MI355X_OK) return prc;
   m.cur = nxt;
   return NBODY_MI355X_OK;
@@ -230,6 +340,7 @@ int sync_all(MultiSim& m, int code, const char* what) {
   for (Shard& s : m.sh) {
     M_TRY(hipSetDevice(s.device), NBODY_MI355X_ERR_NO_DEVICE, "hipSetDevice");
     M_TRY(hipStreamSynchronize(s.stream), code, what);
+    M_TRY(hipStreamSynchronize(s.comm), code, what);
   }
   return NBODY_MI355X_OK;
 }
@@ -238,6 +349,15 @@ int sync_all(MultiSim& m, int code, const char* what) {
 
 int multi_destroy(MultiSim* m) {
   if (!m) return NBODY_MI355X_OK;
+  for (Shard& s : m->sh) {
+    if (s.nccl && m->nccl.CommDestroy) {
+      (void)hipSetDevice(s.device);
+      if (s.stream) (void)hipStreamSynchronize(s.stream);
+      if (s.comm) (void)hipStreamSynchronize(s.comm);
+      (void)m->nccl.CommDestroy(s.nccl);
+      s.nccl = nullptr;
+    }
+  }
   for (Shard& s : m->sh) free_shard(s);
   delete m;
   return NBODY_MI355X_OK;
@@ -288,17 +408,30 @@ int multi_create(const nbody_mi355x_config& cfg, const int32_t* devices, int32_t
   m->sym = wanted && nbody_mi355x_step_workspace_bytes(&probe, &need) == NBODY_MI355X_OK && need > 0;
   m->sym_variant = probe.variant;
 
-  // peers that are different GPUs: direct access where the platform offers it (the pulls
-  // work without it, staged by the runtime)
+  // peers that are different GPUs: direct access where the platform offers it.  Without it
+  // the pulls still work, staged by the runtime through host memory -- slower, so it is said:
+  // the text stays in nbody_mi355x_last_error() after a successful create.
+  int no_peer = 0;
+  bool distinct = true;
   for (int r = 0; r < num; r++)
     for (int q = 0; q < num; q++) {
-      if (devices[r] == devices[q]) continue;
+      if (r == q) continue;
+      if (devices[r] == devices[q]) { distinct = false; continue; }
       int can = 0;
-      if (hipSetDevice(devices[r]) == hipSuccess && hipDeviceCanAccessPeer(&can, devices[r], devices[q]) == hipSuccess &&
-          can)
-        (void)hipDeviceEnablePeerAccess(devices[q], 0);  // "already enabled" is fine
+      hipError_t e = hipSetDevice(devices[r]);
+      if (e == hipSuccess) e = hipDeviceCanAccessPeer(&can, devices[r], devices[q]);
+      if (e == hipSuccess && can) {
+        e = hipDeviceEnablePeerAccess(devices[q], 0);
+        if (e == hipErrorPeerAccessAlreadyEnabled) e = hipSuccess;
+      }
       (void)hipGetLastError();
+      if (e != hipSuccess || !can) {
+        no_peer++;
+        set_error("create_multi: no direct peer access from device %d to device %d (%s): exchanges between them are "
+                  "staged by the runtime", devices[r], devices[q], e != hipSuccess ? hipGetErrorString(e) : "not offered");
+      }
     }
+  (void)no_peer;
 
   const size_t all = sizeof(double) * 3 * static_cast<size_t>(S) * num, one = sizeof(double) * 3 * static_cast<size_t>(S);
   const int64_t eblocks = S / NBODY_MI355X_TILE;
@@ -313,8 +446,10 @@ int multi_create(const nbody_mi355x_config& cfg, const int32_t* devices, int32_t
          hipMalloc(&s.snap, sizeof(double) * 9 * static_cast<size_t>(s.count)) == hipSuccess &&
          hipMalloc(&s.scratch, sizeof(double) * static_cast<size_t>(2 * eblocks + 2)) == hipSuccess &&
          hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) == hipSuccess &&
+         hipStreamCreateWithFlags(&s.comm, hipStreamNonBlocking) == hipSuccess &&
          hipEventCreateWithFlags(&s.ev_partials, hipEventDisableTiming) == hipSuccess &&
          hipEventCreateWithFlags(&s.ev_pos, hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags(&s.ev_gathered, hipEventDisableTiming) == hipSuccess &&
          hipEventCreate(&s.ev_t0) == hipSuccess && hipEventCreate(&s.ev_t1) == hipSuccess;
   }
   if (!ok) {
@@ -345,6 +480,27 @@ int multi_create(const nbody_mi355x_config& cfg, const int32_t* devices, int32_t
       t.acc_all = t.stage = nullptr;
       t.workspace = nullptr;
       t.workspace_bytes = 0;
+    }
+  }
+  // RCCL for the two exchanges: opt-in (see the file header), one communicator over the
+  // listed devices; anything missing -> peer copies, and the reason is left in last_error
+  const char* want = getenv("NBODY_MI355X_MULTI_RCCL");
+  if (want && atoi(want) != 0) {
+    if (!distinct) {
+      set_error("create_multi: NBODY_MI355X_MULTI_RCCL needs every shard on its own GPU; using peer copies");
+    } else if (!load_rccl(&m->nccl)) {
+      set_error("create_multi: librccl could not be loaded (%s); using peer copies", dlerror());
+    } else {
+      std::vector<void*> comms(num, nullptr);
+      std::vector<int> devs(devices, devices + num);
+      const int rc = m->nccl.CommInitAll(comms.data(), num, devs.data());
+      if (rc != 0) {
+        set_error("create_multi: ncclCommInitAll: %s; using peer copies",
+                  m->nccl.GetErrorString ? m->nccl.GetErrorString(rc) : "error");
+      } else {
+        for (int r = 0; r < num; r++) m->sh[r].nccl = comms[r];
+        m->rccl = true;
+      }
     }
   }
   *out = m;
@@ -415,7 +571,7 @@ int multi_enqueue(MultiSim* m, int64_t substeps, double* snapshot_out) {
       if (rc != NBODY_MI355X_OK) return rc;
       M_TRY(hipEventRecord(s.ev_pos, s.stream), NBODY_MI355X_ERR_LAUNCH, "event record");
     }
-    const int prc = pull_positions(*m, nxt);
+    const int prc = gather_positions(*m, nxt);
     if (prc != NBODY_MI355X_OK) return prc;
     m->cur = nxt;
     for (int64_t k = 0; k + 1 < substeps; k++) {
@@ -432,6 +588,8 @@ int multi_enqueue(MultiSim* m, int64_t substeps, double* snapshot_out) {
   }
   for (Shard& s : m->sh) {
     M_TRY(hipSetDevice(s.device), NBODY_MI355X_ERR_NO_DEVICE, "hipSetDevice");
+    // (the big step is complete when the last exchange is: it belongs inside the timed span)
+    M_TRY(hipStreamWaitEvent(s.stream, s.ev_gathered, 0), NBODY_MI355X_ERR_LAUNCH, "wait exchange");
     M_TRY(hipEventRecord(s.ev_t1, s.stream), NBODY_MI355X_ERR_LAUNCH, "event record");
     if (snapshot_out)
       M_TRY(hipMemcpyAsync(snapshot_out + 9 * s.begin, s.snap, sizeof(double) * 9 * static_cast<size_t>(s.count),

@@ -111,7 +111,8 @@ extern "C" int nbody_mi355x_create_multi(const nbody_mi355x_config* cfg, const i
   *out = nullptr;
   int rc = check_config(cfg);
   if (rc != NBODY_MI355X_OK) return rc;
-  if (num_devices == 1) {  // one shard is the plain handle
+  const char* force = getenv("NBODY_MI355X_MULTI_FORCE");  // tests: one shard through the multi-shard code
+  if (num_devices == 1 && !(force && atoi(force) != 0)) {  // one shard is the plain handle
     nbody_mi355x_config one = *cfg;
     one.device = devices[0];
     return nbody_mi355x_create(&one, out);

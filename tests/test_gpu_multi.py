@@ -97,3 +97,61 @@ def test_multi_errors():
         p, m = nb.ic_plummer(100, 1)
         sim.upload(p, m)
         assert sim.run(2).shape == (100, 9)
+
+
+def _rccl_one_rank_main(n, q):
+    """Own process (the two environment switches are read at create): one shard through the
+    multi-shard code with its exchanges done by RCCL -- ncclCommInitAll over one device,
+    in-place ncclAllGather of the positions, ncclReduceScatter of the partial sums."""
+    import os
+    import sys
+    from pathlib import Path
+    repo = Path(__file__).resolve().parent.parent
+    sys.path.insert(0, str(repo / "n-body-sim_amd"))
+    os.environ["NBODY_MI355X_MULTI_FORCE"] = "1"
+    os.environ["NBODY_MI355X_MULTI_RCCL"] = "1"
+    import torch  # noqa: F401  (maps torch's librccl: the library must pick that copy up)
+    import nbody_mi355x as nb
+    p, m = nb.ic_plummer(n, 13)
+    with nb.Simulation(n, 1e-3, devices=[0]) as sim:
+        text = nb.last_error()              # create leaves a note here if it fell back to peer copies
+        sim.upload(p, m)
+        outs = [sim.run(3, snapshot=True) for _ in range(2)]
+        fin = sim.download()
+    q.put((text, outs, fin))
+
+
+@pytest.mark.parametrize("n", [1500, 20000])
+def test_rccl_exchanges_with_a_one_rank_communicator(n):
+    """NBODY_MI355X_MULTI_RCCL=1: the C library's own RCCL path (resolved with dlopen, no link
+    dependency) with the one rank a one-GPU box allows, one-sided (1500) and pair-symmetric
+    (20 000: phases 1 and 2 around the exchange, reduce-scatter of the partial sums)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    pr = ctx.Process(target=_rccl_one_rank_main, args=(n, q))
+    pr.start()
+    text, outs, fin = q.get(timeout=200)
+    pr.join(timeout=60)
+    assert pr.exitcode == 0
+    assert "peer copies" not in text, text     # RCCL was loaded and the communicator built
+    p, m = nb.ic_plummer(n, 13)
+    fin_ref, ref = ol.simulate(p, m, 2, 3, 1e-3, threads=16)
+    for k in range(2):
+        assert rel_pos_err(outs[k][:, :3], ref[k, :, :3]) <= 1e-13
+        num = np.linalg.norm(outs[k][:, 6:9] - ref[k, :, 6:9], axis=1)
+        assert (num / np.linalg.norm(ref[k, :, 6:9], axis=1)).max() <= 1e-12
+    assert rel_pos_err(fin[:, :3], fin_ref[:, :3]) <= 1e-13
+
+
+def test_multi_overlap_many_steps_bit_reproducible():
+    """The split step (diagonal tiles under the exchange on the comm stream, the rest after it)
+    over 40 small steps on 8 shards: same bits run to run -- any event missing between the
+    compute and comm streams would show as a difference or as an error against the oracle."""
+    n = 24000
+    p, m = nb.ic_plummer(n, 5)
+    fin_a, a, _ = multi_simulate(p, m, 8, 2, 20, 1e-3)
+    fin_b, b, _ = multi_simulate(p, m, 8, 2, 20, 1e-3)
+    assert np.array_equal(a, b) and np.array_equal(fin_a, fin_b)
+    _, ref = ol.simulate(p, m, 2, 20, 1e-3, threads=16)
+    assert rel_pos_err(a[1, :, :3], ref[1, :, :3]) <= 1e-12
