@@ -48,10 +48,12 @@ typedef enum {
 /* Arithmetic of the force accumulation. */
 #define NBODY_MI355X_FP64 0 /* everything in double (parity path)                */
 #define NBODY_MI355X_FP32 1 /* forces MAY be evaluated in float: r^2, r^-3 and the running
-                               sums (and, in the pair-symmetric kernels, the separations);
-                               state, integration and snapshots stay double.  Systems of
-                               at most NBODY_MI355X_WAVE_MAX_BODIES bodies are latency-bound
-                               and run the double kernels either way (faster there)     */
+                               sums; in the pair-symmetric kernels also the separations, taken
+                               from coordinates RELATIVE to the row's centroid (subtracted in
+                               double, then narrowed), so that a system far from the origin
+                               loses nothing; state, integration and snapshots stay double.
+                               Systems of at most NBODY_MI355X_WAVE_MAX_BODIES bodies are
+                               latency-bound and run the double kernels either way (faster there) */
 
 /* Time integrator fused into the step's epilogue.
  * EULER: the reference's forward Euler, v' = v + dt a, r' = r + dt v (OLD v)
@@ -185,8 +187,11 @@ int nbody_mi355x_kdk_drift_f64(const nbody_mi355x_step_args* args, void* stream)
 int nbody_mi355x_step_variant(const nbody_mi355x_step_args* args, int32_t* variant);
 
 /* Scratch the pair-symmetric form of the step needs for these args (fields
- * shard_slots, num_shards, variant are read): *bytes = 0 if that form does not
- * apply (more than one slab, slot count not a multiple of its block, ...).
+ * shard_slots, num_shards, variant, precision are read): *bytes = the preferred size --
+ * every block distance at once, capped at 4 GiB (or four times the minimum); any size from
+ * the minimum up is accepted by the step, which then walks the distances in batches --
+ * or 0 if that form does not apply (slot count not a multiple of the block, fewer than two
+ * blocks).  Several slabs are fine (the step then needs acc_out, see `phase`).
  * The symmetric kernels evaluate each unordered pair once (Newton's third law)
  * and reduce partial sums through this workspace in a fixed order: same maths,
  * different summation order, bit-reproducible.  No counterpart in the reference. */

@@ -14,14 +14,16 @@ struct alignas(32) JBody {
   double x, y, z, m;
 };
 
-// 2^-600.  With eps2 == 0 the kernel adds this to r^2 inside the first FMA of
-// the r^2 chain.  For any pair a simulation can hold apart (r > 1e-82 in the
-// unit of length) r^2 + 2^-600 rounds to r^2, so the value is bit-for-bit the
+// 2^-300.  With eps2 == 0 the kernel adds this to r^2 inside the first FMA of
+// the r^2 chain.  For any pair a simulation can hold apart (r > 6e-38 in the
+// unit of length) r^2 + 2^-300 rounds to r^2, so the value is bit-for-bit the
 // unsoftened one; for r^2 == 0 (i == j, or coincident bodies) it makes
-// rsq finite (2^300), m * 2^900 stays finite for m < 2^124, and the pair
-// contributes s * 0 = 0: exactly the reference's `if (r_squared != 0)`
-// (particle_simulation.h:269) without a compare or a select.
-constexpr double kTinyR2 = 0x1p-600;
+// rsq finite (2^150), m * 2^450 stays finite for |m| < 2^574 (1e172: any mass a
+// double-precision scene holds, SI units included), and the pair contributes
+// s * 0 = 0: exactly the reference's `if (r_squared != 0)`
+// (particle_simulation.h:269) without a compare or a select.  (A smaller seed
+// buys nothing and costs mass range: 2^-600 overflowed m * y0^3 from 2^124 = 2e37 kg up.)
+constexpr double kTinyR2 = 0x1p-300;
 
 // One interaction in double: 16 FP64 VALU operations + v_rsq_f64:
 //   3 sub, 3 fma (r^2), rsq, 7 for m * r^-3 (below), 3 fma (accumulate).

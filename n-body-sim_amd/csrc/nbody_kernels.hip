@@ -15,7 +15,7 @@
 //     (2 x ds_read_b128 per j, amortised over IPT interactions);
 //   * r^-3 from v_rsq_f64 plus a folded series correction, no division, no
 //     sqrt, no branch: the r^2 == 0 rule is kept exactly by seeding the r^2 FMA
-//     chain with 2^-600 (see pair_f64), which costs no instruction;
+//     chain with 2^-300 (see pair_f64), which costs no instruction;
 //   * the Euler update and the optional snapshot are fused into the epilogue.
 // FP64 vector FMA is the bounding unit (no MFMA: this is not a contraction).
 #include <hip/hip_runtime.h>
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(kTile) void step_kernel(const nbody_mi355x_step_arg
   __shared__ JBody tile[2][kTile];
   const int tid = threadIdx.x;
   const int64_t S = a.shard_slots;
-  // double path: 2^-600 stands in for "no softening" (see kTinyR2); float path: plain 0
+  // double path: 2^-300 stands in for "no softening" (see kTinyR2); float path: plain 0
   const double eps2 = (a.eps2 > 0.0) ? a.eps2 : (sizeof(Acc) == sizeof(double) ? kTinyR2 : 0.0);
   double c15 = 1.5, c1875 = 1.875;  // opaque to the optimiser: stay in VGPRs (see pair_f64)
   asm volatile("" : "+v"(c15), "+v"(c1875));

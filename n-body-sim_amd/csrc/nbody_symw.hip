@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void sym_wave_kernel(const SymArgs a) {
   const int il = blockIdx.x, c = blockIdx.y;  // own row (local index), chunk of its list
   const int I = a.row0 + il;
   const int64_t S = a.S;
-  // double: 2^-600 stands in for "no softening" (nbody_device.hpp); float: plain 0 + a select
+  // double: 2^-300 stands in for "no softening" (nbody_device.hpp); float: plain 0 + a select
   const T eps2 = static_cast<T>((a.eps2 > 0.0) ? a.eps2 : (kDouble ? kTinyR2 : 0.0));
   T c15 = static_cast<T>(1.5), c1875 = static_cast<T>(1.875);
   asm volatile("" : "+v"(c15), "+v"(c1875));

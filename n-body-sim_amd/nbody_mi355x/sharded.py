@@ -133,7 +133,7 @@ class ShardedNBody:
                 if self.multi:
                     self.acc_all = torch.zeros((world, 3, S), dtype=torch.float64, device=dev)
         self.sym_variant = variant if variant in SYM_VARIANTS else VARIANT_SYM
-        self._send = None
+        self._send = self._recv = None
         self.cur = 0
         self._fresh = True  # every slab of pos[cur] is current (true right after upload)
 
@@ -196,22 +196,41 @@ class ShardedNBody:
     def _all_gather(self, buf, async_op):
         import torch.distributed as dist
         flat = buf.view(-1)
-        own = flat[self.rank * 3 * self.S:(self.rank + 1) * 3 * self.S]
+        n3 = 3 * self.S
+        own = flat[self.rank * n3:(self.rank + 1) * n3]
         if dist.get_backend(self.group) == "nccl" or buf.device.type == "cpu":
-            # ONE collective: every rank's slab (3*S doubles) into its place in the slab
-            # layout.  The send side is a private copy of the own slab (a 3*S-double device
-            # copy, microseconds) so that input and output never alias.
+            # ONE collective: every rank's slab (3*S doubles).  Neither side of it aliases
+            # memory a kernel is using: the send side is a private copy of the own slab and the
+            # receive side a staging tensor -- the own-slab kernels (phase 1) read `buf` while
+            # the collective is in flight on RCCL's stream; the REMOTE slabs are copied into
+            # their places (two device copies, microseconds) after the wait, in stream order.
             if self._send is None:
                 self._send = torch.empty_like(own)
+                self._recv = torch.empty_like(flat)
             self._send.copy_(own)
-            return dist.all_gather_into_tensor(flat, self._send, group=self.group, async_op=async_op)
+            work = dist.all_gather_into_tensor(self._recv, self._send, group=self.group, async_op=async_op)
+            lo, hi, recv = self.rank * n3, (self.rank + 1) * n3, self._recv
+
+            class _Placed:
+                def wait(self_inner):
+                    if work is not None:
+                        work.wait()              # stream-ordered, not a host block
+                    if lo > 0:
+                        flat[:lo].copy_(recv[:lo])
+                    if hi < flat.numel():
+                        flat[hi:].copy_(recv[hi:])
+                    return True
+            placed = _Placed()
+            if not async_op:
+                placed.wait()
+            return placed
         # gloo with device tensors (rehearsals): staged via the host, out of place
         mine = own.cpu()
         parts = [torch.empty_like(mine) for _ in range(self.world)]
         dist.all_gather(parts, mine, group=self.group)
         for r, part in enumerate(parts):
             if r != self.rank:
-                flat[r * 3 * self.S:(r + 1) * 3 * self.S].copy_(part)
+                flat[r * n3:(r + 1) * n3].copy_(part)
 
         class _Done:
             def wait(self):

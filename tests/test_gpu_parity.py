@@ -706,3 +706,25 @@ def test_run_async_failure_leaves_the_handle_consistent():
         assert e.value.code == nb.ERR_LAUNCH and "launch" in str(e.value)
         sim.wait()
         assert np.array_equal(sim.download(), p)
+
+
+@pytest.mark.parametrize("n,kw", [(40, {}), (700, {}), (700, {"variant": 2}), (9000, {}), (9000, {"variant": 14}),
+                                  (9000, {"no_eq": True})])
+def test_very_large_masses_do_not_poison_the_self_pair(n, kw, monkeypatch):
+    """A body of 1e40 kg (above 2^124): its own pair (r^2 == 0) must still contribute exactly
+    nothing.  The r^2 == 0 rule is kept by seeding the r^2 chain with 2^-300 (nbody_device.hpp):
+    m * rsq(2^-300)^3 = m * 2^450 stays finite for any such mass, where the former 2^-600 seed
+    overflowed to inf and inf * 0 made every body NaN one step later.  ref: the reference skips
+    the pair, particle_simulation.h:269."""
+    kw = dict(kw)
+    if kw.pop("no_eq", False):
+        monkeypatch.setenv("NBODY_MI355X_SYM_NOEQ", "1")
+    p, m = nb.ic_plummer(n, 21)
+    m = m.copy()
+    m[n // 2] = 1e40
+    m[n // 3] = 3e38
+    _, ref = ol.simulate(p, m, 1, 2, 1e-9, threads=8)
+    _, out = gpu_simulate(p, m, 1, 2, 1e-9, **kw)
+    assert np.all(np.isfinite(out))
+    assert rel_pos_err(out[0, :, :3], ref[0, :, :3]) <= 1e-13
+    assert vec_rel(out[0, :, 6:9], ref[0, :, 6:9]) <= 1e-12
