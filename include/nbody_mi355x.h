@@ -156,13 +156,13 @@ typedef struct {
 #define NBODY_MI355X_VARIANT_SYM1 11 /* pair-symmetric, 256-body blocks  */
 #define NBODY_MI355X_VARIANT_SYM2 12 /* pair-symmetric, 512-body blocks  */
 #define NBODY_MI355X_VARIANT_SYM4 14 /* pair-symmetric, 1024-body blocks */
-#define NBODY_MI355X_VARIANT_SYM8 18 /* pair-symmetric, 2048-body blocks (FP64 only) */
+#define NBODY_MI355X_VARIANT_SYM8 18 /* pair-symmetric, 2048-body blocks */
 /* pair-symmetric with WAVE tiles (mid-size systems): a workgroup's 4 waves hold the same
  * 64, 128, 256 or 512 bodies and each takes its own groups of 64 j bodies */
 #define NBODY_MI355X_VARIANT_SYMW1 21
 #define NBODY_MI355X_VARIANT_SYMW2 22
 #define NBODY_MI355X_VARIANT_SYMW4 24
-#define NBODY_MI355X_VARIANT_SYMW8 28 /* (FP64 only) */
+#define NBODY_MI355X_VARIANT_SYMW8 28
 
 /* One small step (or one half of a split one) for the own slab's bodies:
  * a_i = sum_j m_j (r_j - r_i) / |r_j - r_i|^3 over the j ranges, then

@@ -405,7 +405,7 @@ double plan_for(const nbody_mi355x_step_args& a, int ipt, Plan* p) {
   // rises with the number of chunks up to ~16-32 and is flat beyond, and what is left is
   // the tail of one work item; so: up to 32 chunks, and tiles split until there are ~32
   // items per CU.  Model time = work / 256 CUs + one item at full CU residency.
-  if (ipt == 8 && a.precision == NBODY_MI355X_FP32) return -1.0;  // (not instantiated for float)
+  if (ipt == 8 && a.precision == NBODY_MI355X_FP32 && env_int("NBODY_MI355X_F32_NO8")) return -1.0;  // (A/B tests)
   const int per_cu = ipt >= 4 ? 2 : (ipt == 2 ? 4 : 8);
   // 6 DPP moves per IPT pairs on top of 96 cycles of FP64 work per pair
   const double pair_cost = ipt == 8 ? 0.97 : (ipt == 4 ? 1.00 : (ipt == 2 ? 1.05 : 1.15));
@@ -458,7 +458,7 @@ constexpr int64_t kWaveTileMaxSlots = 196608;  // wave tiles up to here, workgro
 double plan_wave(const nbody_mi355x_step_args& a, int ipt, Plan* p) {
   const int64_t B = 64 * ipt;
   if (a.num_shards < 1 || a.shard_slots <= 0 || a.shard_slots % B != 0) return -1.0;
-  if (ipt == 8 && a.precision == NBODY_MI355X_FP32) return -1.0;  // (not instantiated for float)
+  if (ipt == 8 && a.precision == NBODY_MI355X_FP32 && env_int("NBODY_MI355X_F32_NO8")) return -1.0;  // (A/B tests)
   p->wave = true;
   p->block = B;
   p->ipt = ipt;
@@ -579,7 +579,8 @@ hipError_t launch_tiles(const Plan& p, bool fp32, const SymArgs& sa, dim3 grid, 
   if (p.wave) return nbody_sym::launch_wave_tiles(p.ipt, fp32, sa, grid, stream);
   if (fp32)
     return p.ipt == 1 ? launch_wg_tiles<1, float>(sa, grid, stream)
-           : p.ipt == 2 ? launch_wg_tiles<2, float>(sa, grid, stream) : launch_wg_tiles<4, float>(sa, grid, stream);
+           : p.ipt == 2 ? launch_wg_tiles<2, float>(sa, grid, stream)
+           : p.ipt == 4 ? launch_wg_tiles<4, float>(sa, grid, stream) : launch_wg_tiles<8, float>(sa, grid, stream);
   return p.ipt == 1 ? launch_wg_tiles<1, double>(sa, grid, stream)
          : p.ipt == 2 ? launch_wg_tiles<2, double>(sa, grid, stream)
          : p.ipt == 4 ? launch_wg_tiles<4, double>(sa, grid, stream) : launch_wg_tiles<8, double>(sa, grid, stream);

@@ -225,6 +225,7 @@ hipError_t launch_wave_tiles(int ipt, bool fp32, const SymArgs& sa, dim3 grid, h
       case 1: return launch_one<1, float>(sa, grid, stream);
       case 2: return launch_one<2, float>(sa, grid, stream);
       case 4: return launch_one<4, float>(sa, grid, stream);
+      case 8: return launch_one<8, float>(sa, grid, stream);
       default: return hipErrorInvalidValue;
     }
   }

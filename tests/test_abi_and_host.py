@@ -149,7 +149,7 @@ def test_step_variant_reports_the_kernel_choice_without_a_gpu():
     assert variant_of(100000) in (1, 2) and variant_of(1048576) == 2          # no workspace: one-sided
     assert variant_of(8192, big) == nb.VARIANT_SYMW2 and variant_of(16384, big) == nb.VARIANT_SYMW4
     assert variant_of(65536, big) == nb.VARIANT_SYMW8 and variant_of(1048576, big) == nb.VARIANT_SYM8
-    assert variant_of(65536, big, precision=nb.FP32) == nb.VARIANT_SYMW4      # (no 512-body float build)
+    assert variant_of(65536, big, precision=nb.FP32) == nb.VARIANT_SYMW8 and variant_of(1048576, big, precision=nb.FP32) == nb.VARIANT_SYM8
     assert variant_of(65536, 4096) in (1, 2)                                  # workspace below the minimum
     assert variant_of(20000, big, variant=nb.VARIANT_SYM4) == nb.VARIANT_SYM4
     assert variant_of(20000, 0, variant=3) == 3
