@@ -454,7 +454,7 @@ double plan_for(const nbody_mi355x_step_args& a, int ipt, Plan* p) {
 // 8192 bodies, 128-body blocks: 39.3; 16 384, 256: 108; 32 768, 512: 379; 65 536, 512: 1420.
 // Sizes that are not powers of two are where the model earns its keep: 12 288 bodies with a
 // fixed per = 16 are 288 full items on 256 CUs -- two rounds for 1.1 rounds' work (97 us).
-constexpr int64_t kWaveTileMaxSlots = 196608;  // wave tiles up to here, workgroup tiles beyond
+constexpr int64_t kWaveTileMaxSlots = 262143;  // wave tiles up to here, workgroup tiles beyond
 double plan_wave(const nbody_mi355x_step_args& a, int ipt, Plan* p) {
   const int64_t B = 64 * ipt;
   if (a.num_shards < 1 || a.shard_slots <= 0 || a.shard_slots % B != 0) return -1.0;
@@ -526,7 +526,8 @@ bool make_plan(const nbody_mi355x_step_args& a, Plan* p) {
   // MI355X (Ginteractions/s, equal masses; workgroup tiles of the best block in brackets):
   // 8192 bodies: 128-body blocks 1707, 256: 1657, 64: 1467 (1177); 16 384: 256: 2487, 512: 2297
   // (1893); 32 768: 256: 2861, 512: 2830 (2578); 65 536: 512: 3025, 256: 2978 (2857); 131 072:
-  // 512: 3019 (2985); 262 144: 2938 (2936); 524 288: 2969 (3012); 1 048 576: 2971 (3040) --
+  // 512: 3019 (2985); 198 656: (2692, 1024-body blocks: too few 2048-body tiles); 262 144: 2938
+  // (2936 .. 2966); 524 288: 2969 (3012); 1 048 576: 2971 (3040) --
   // the j-side sums are stored after meeting 512 bodies instead of 2048, traffic that grows
   // as N^2, so the large systems keep workgroup tiles.
   {

@@ -196,7 +196,7 @@ def test_config3_plummer_65536_full_trajectory():
     assert rel_pos_err(out[0, :, :3], ref[0, :, :3]) <= 1e-11
 
 
-@pytest.mark.parametrize("n", [65536, 1048576])
+@pytest.mark.parametrize("n", [65536, 196609, 260096, 262144, 1048576])
 def test_full_size_sampled_rows_and_momentum(n):
     """BASELINE sizes: the oracle cannot run the full step, so (a) exact accelerations for
     1024 sampled rows against all n bodies, (b) sum_i m_i a_i = 0 (Newton's third law,
@@ -728,3 +728,22 @@ def test_very_large_masses_do_not_poison_the_self_pair(n, kw, monkeypatch):
     assert np.all(np.isfinite(out))
     assert rel_pos_err(out[0, :, :3], ref[0, :, :3]) <= 1e-13
     assert vec_rel(out[0, :, 6:9], ref[0, :, 6:9]) <= 1e-12
+
+
+def test_small_workspace_cap_batches_the_distances(monkeypatch):
+    """The handle takes a workspace of at most 4 GiB (or four times the plan's minimum) and walks
+    the block distances in batches that reuse it; here the cap is forced down to 24 MB for a
+    system whose unbatched workspace is 49 MB: several batches per small step, same answer."""
+    n = 40000
+    p, m = nb.ic_plummer(n, 19)
+    with nb.Simulation(n, 1e-3) as sim:
+        _, full = sim.kernel_in_use()
+    monkeypatch.setenv("NBODY_MI355X_SYM_WS_CAP_MB", "24")
+    with nb.Simulation(n, 1e-3) as sim:
+        variant, capped = sim.kernel_in_use()
+        sim.upload(p, m)
+        out = sim.run(3, snapshot=True)
+    assert variant in nb.SYM_VARIANTS and capped <= 0.6 * full
+    _, ref = ol.simulate(p, m, 1, 3, 1e-3, threads=16)
+    assert rel_pos_err(out[:, :3], ref[0, :, :3]) <= 1e-14
+    assert vec_rel(out[:, 6:9], ref[0, :, 6:9]) <= 1e-12

@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """Summarise a tools/profile.sh output directory: per-kernel averages of every counter,
 kernel-trace stats, and derived figures for the step kernel.  Usage:
-    python tools/summarize_pmc.py gpurun_out/TAG N_BODIES > profiles/NAME.txt"""
+    python tools/summarize_pmc.py gpurun_out/TAG N_BODIES [KERNEL_SUBSTRING [STEPS]] > profiles/NAME.txt
+STEPS = small steps the profiled command ran (bench.py: --steps + --warmup): a step may take
+several launches of one kernel (distance batches), so the per-interaction figures are taken per
+STEP (sum over the step's launches), not per launch."""
 import collections
 import csv
 import glob
@@ -9,6 +12,7 @@ import sys
 
 d, n = sys.argv[1], float(sys.argv[2])
 sel = sys.argv[3] if len(sys.argv) > 3 else "step"
+steps = float(sys.argv[4]) if len(sys.argv) > 4 else 0.0
 for f in glob.glob(f"{d}/trace/vm/*_kernel_stats.csv"):
     print("== kernel-trace stats (rocprofv3 --kernel-trace --stats) ==")
     print(open(f).read())
@@ -29,7 +33,12 @@ for k, cs in c.items():
     t = sum(dur[k]) / len(dur[k])
     g = {a: sum(v) / len(v) for a, v in cs.items()}
     pairs = n * n / 64.0
-    print(f"  avg duration under PMC      {t:.4f} s")
+    print(f"  avg duration under PMC      {t:.4f} s per launch")
+    if steps > 0:
+        calls = max(len(v) for v in cs.values())
+        per_step = calls / steps
+        pairs = pairs / per_step     # (the figures below: per 64 interactions of a whole STEP)
+        print(f"  launches per step           {per_step:g}   ({t * per_step:.4f} s per step)")
     if "SQ_INSTS_VALU" in g:
         print(f"  VALU wave-instr per 64 interactions   {g['SQ_INSTS_VALU']/pairs:.2f}")
     if "SQ_ACTIVE_INST_VALU" in g:
