@@ -382,7 +382,7 @@ void plan_bytes(const nbody_mi355x_step_args& a, Plan* p) {
   const int64_t least = p->row_bytes * (fixed_rows(*p, a.num_shards) + 1);
   int64_t cap = kBatchCap > 4 * least ? kBatchCap : 4 * least;
   if (const int mb = env_int("NBODY_MI355X_SYM_WS_CAP_MB"); mb > 0) cap = static_cast<int64_t>(mb) << 20;
-  p->bytes = full <= cap ? full : (least > cap ? least : cap);
+  p->bytes = full <= cap ? full : (least > cap ? least : cap / p->row_bytes * p->row_bytes);  // whole rows
 }
 
 // One candidate block size of the workgroup-tile kernels: fills *p and returns its modelled

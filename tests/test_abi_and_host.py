@@ -155,3 +155,34 @@ def test_step_variant_reports_the_kernel_choice_without_a_gpu():
     assert variant_of(20000, 0, variant=3) == 3
     a = nb.StepArgs()
     assert L.nbody_mi355x_step_variant(C.byref(a), C.byref(C.c_int32())) == nb.ERR_INVALID
+
+
+def test_launch_plans_exist_and_are_consistent_for_every_layout():
+    """The plan of the pair-symmetric kernels is a pure function of (slots, slabs, variant,
+    precision): for every slab size from 2 blocks up, one slab or several, the workspace query
+    and the variant query must agree, the preferred workspace must respect the 4 GiB cap (or
+    four times the minimum), and no layout may be left without a kernel.  No launch: runs here."""
+    import ctypes as C
+    L = nb.lib()
+    sizes = list(range(256, 16384, 256)) + list(range(16384, 300000, 7 * 1024)) + [1 << 20, 3 << 20, 1 << 22]
+    for shards in (1, 2, 3, 8):
+        for prec in (nb.FP64, nb.FP32):
+            for S in sizes:
+                a = nb.StepArgs()
+                a.pos_cur, a.pos_next, a.mass, a.vel, a.acc_out = 8, 16, 8, 8, (8 if shards > 1 else None)
+                a.shard_slots, a.num_shards, a.own_count, a.precision = S, shards, S, prec
+                a.variant = nb.VARIANT_SYM
+                need, v = C.c_int64(-1), C.c_int32(-1)
+                nb.check(L.nbody_mi355x_step_workspace_bytes(C.byref(a), C.byref(need)))
+                total = S * shards
+                if total < 128:
+                    continue
+                assert need.value > 0, (S, shards, prec)
+                assert need.value % (24 * S) == 0                     # whole rows of 3*S doubles
+                assert need.value <= max(4 << 30, 4 * 24 * S * 80)    # capped (80 rows: a generous bound on the minimum)
+                a.workspace, a.workspace_bytes = 8, need.value
+                nb.check(L.nbody_mi355x_step_variant(C.byref(a), C.byref(v)))
+                assert v.value in nb.SYM_VARIANTS and v.value != nb.VARIANT_SYM, (S, shards, prec, v.value)
+                block = {11: 256, 12: 512, 14: 1024, 18: 2048, 21: 64, 22: 128, 24: 256, 28: 512}[v.value]
+                assert S % block == 0 and total // block >= 2
+                assert (v.value > 20) == (total <= 262143), (S, shards, v.value)   # wave tiles up to 262 143 slots
