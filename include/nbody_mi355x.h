@@ -261,7 +261,10 @@ int nbody_mi355x_create(const nbody_mi355x_config* cfg, nbody_mi355x_sim** sim);
  * by peer copies ordered with events; the host does not block inside a big
  * step.  A device ordinal may appear more than once (several shards on one GPU:
  * how the path is rehearsed on a one-GPU machine).  cfg->device is ignored.
- * Every other handle function works on the result unchanged. */
+ * Every other handle function works on the result unchanged.  On success
+ * nbody_mi355x_last_error() is empty, or holds a note: direct peer access between two of
+ * the devices could not be enabled (the runtime then stages those copies through the host),
+ * or NBODY_MI355X_MULTI_RCCL=1 was set and RCCL could not be used (peer copies instead). */
 int nbody_mi355x_create_multi(const nbody_mi355x_config* cfg, const int32_t* devices,
                               int32_t num_devices, nbody_mi355x_sim** sim);
 /* ref: FreeDeviceMemory, particle_simulation_GPU.cu:216-231. */

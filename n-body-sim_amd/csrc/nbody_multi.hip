@@ -365,6 +365,7 @@ int multi_destroy(MultiSim* m) {
 
 int multi_create(const nbody_mi355x_config& cfg, const int32_t* devices, int32_t num, MultiSim** out) {
   *out = nullptr;
+  set_error("%s", "");  // (a successful create may leave a note here: staged peer copies, RCCL not taken)
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
     (void)hipGetLastError();

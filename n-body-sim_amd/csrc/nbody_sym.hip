@@ -26,7 +26,12 @@
 //     results are bit-reproducible run to run.
 //   * d = 0 (the diagonal tile) is evaluated one-sided.
 //
-// Launch shape (make_plan below): grid = (own rows, dsplit distance chunks, jsplit parts of
+// This file holds the WORKGROUP-tile kernel (the large systems), the finishing kernels and the
+// launch plans of both pair-symmetric families; the WAVE-tile kernel for the mid sizes, which
+// shares the arithmetic (nbody_sym_device.hpp) and everything downstream of the tiles, is
+// nbody_symw.hip.  make_plan picks the family and the block size.
+//
+// Launch shape of the workgroup tiles (plan_for below): grid = (own rows, dsplit distance chunks, jsplit parts of
 // a tile's j groups).  dsplit and jsplit only exist to put >= 2 waves' worth of workgroups
 // on each of the 256 CUs when there are few block rows; each extra part costs one more
 // R slab to add up.  When the C slabs for all nb/2+1 distances do not fit in the caller's
@@ -770,7 +775,7 @@ extern "C" int nbody_mi355x_step_f64_static(const nbody_mi355x_step_args* args, 
   int64_t preferred = 0, least = 0;
   if (!nbody_internal::sym_supported(a, &preferred, &least)) {
     set_error("step_f64_static: the pair-symmetric step does not apply to %d slab(s) of %lld slots "
-              "(at least two blocks of 256 slots are needed)", a.num_shards, (long long)a.shard_slots);
+              "(at least two blocks of the variant's size are needed)", a.num_shards, (long long)a.shard_slots);
     return NBODY_MI355X_ERR_INVALID;
   }
   if (least > static_cast<int64_t>(NBODY_MI355X_STATIC_SCRATCH_BYTES)) {

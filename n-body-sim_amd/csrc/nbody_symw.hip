@@ -1,5 +1,5 @@
 // nbody_symw.hip -- the pair-symmetric small step with WAVE tiles: the mid-size systems
-// (about 8 000 .. 100 000 bodies on a GPU), where a launch of workgroup tiles (nbody_sym.hip)
+// (4097 bodies .. 262 143 slots on a GPU), where a launch of workgroup tiles (nbody_sym.hip)
 // is a few hundred big work items on 1024 SIMDs -- mostly ramp and tail -- and smaller
 // workgroup tiles pay for it with 6 DPP moves per pair instead of per 8.
 //
@@ -16,8 +16,9 @@
 //     is met by exactly one wave, so nothing is added across waves on the j side;
 //   * the i-side sums of the 4 waves are added through LDS in wave order at the end and
 //     stored once per workgroup to R[c][I].
-// Work items are 64 x 64*IPT pairs (a few microseconds) instead of whole tiles; with ~16
-// workgroups per CU the hardware's dynamic dispatch levels the load to within one item.
+// Work items are 64 x 64*IPT pairs (3 .. 21 microseconds) instead of whole tiles; how many a
+// workgroup takes (`per`) and the block size come from a model of the launch (plan_wave,
+// nbody_sym.hip).
 // The price is C traffic that grows as N^2 / (64*IPT) (each j sum is stored after meeting
 // 64*IPT bodies instead of 256*IPT): that is why the large systems keep workgroup tiles.
 // No atomics: bit-reproducible run to run.
