@@ -747,3 +747,27 @@ def test_small_workspace_cap_batches_the_distances(monkeypatch):
     _, ref = ol.simulate(p, m, 1, 3, 1e-3, threads=16)
     assert rel_pos_err(out[:, :3], ref[0, :, :3]) <= 1e-14
     assert vec_rel(out[:, 6:9], ref[0, :, 6:9]) <= 1e-12
+
+
+@pytest.mark.parametrize("n,kw", [(300, {}), (5000, {})])
+def test_kdk_through_graph_replay(n, kw):
+    """Many leapfrog small steps of a small system: the fused {kick, kick, drift} steps are
+    replayed from a hipGraph (64 per replay) between the opening drift and the closing kick; two
+    big steps with an odd number of small steps (the buffer parity flips between them)."""
+    p, m = nb.ic_plummer(n, 33)
+    dt = 1e-3
+    with nb.Simulation(n, dt, integrator=nb.KDK, **kw) as sim:
+        sim.upload(p, m)
+        a = sim.run(200, snapshot=True)
+        b = sim.run(131, snapshot=True)
+        fin = sim.download()
+    with nb.Simulation(n, dt, integrator=nb.KDK, variant=2) as sim:   # one-sided, launched step by step (no graph below 2 * 64 steps)
+        sim.upload(p, m)
+        ref = [sim.run(100, snapshot=True) for _ in range(2)][-1]
+        ref_b = [sim.run(s, snapshot=True) for s in (100, 31)][-1]
+    assert rel_pos_err(a[:, :3], ref[:, :3]) <= 1e-12 and vec_rel(a[:, 3:6], ref[:, 3:6]) <= 1e-10
+    assert rel_pos_err(b[:, :3], ref_b[:, :3]) <= 1e-12 and vec_rel(b[:, 3:6], ref_b[:, 3:6]) <= 1e-10
+    assert np.array_equal(fin, b[:, :6])
+    if n <= 300:
+        r, v, _ = _kdk_reference(p, m, dt, 331)
+        assert rel_pos_err(b[:, :3], r) <= 1e-11
