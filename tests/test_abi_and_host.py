@@ -186,3 +186,10 @@ def test_launch_plans_exist_and_are_consistent_for_every_layout():
                 block = {11: 256, 12: 512, 14: 1024, 18: 2048, 21: 64, 22: 128, 24: 256, 28: 512}[v.value]
                 assert S % block == 0 and total // block >= 2
                 assert (v.value > 20) == (total <= 262143), (S, shards, v.value)   # wave tiles up to 262 143 slots
+
+
+def test_header_is_plain_c():
+    """The boundary is a C ABI: the header must compile as C99 on its own (no C++, no HIP)."""
+    import subprocess
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-fsyntax-only", "-x", "c",
+                    str(REPO / "include" / "nbody_mi355x.h")], check=True)
