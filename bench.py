@@ -352,7 +352,7 @@ def main():
             "vs_baseline": None, "dtype": "f64" if prec == nb.FP64 else "f32", "data": "synthetic",
             "config": {"workload": scene,
                        "bodies": n, "interactions_per_step": inter_per_step,
-                       "parallelism": (f"i-shard x{world}, RCCL all-gather of positions"
+                       "parallelism": (f"i-shard x{world}, {'RCCL' if args.backend == 'nccl' else args.backend + ' (rehearsal, host-staged)'} all-gather of positions"
                                        + (" + reduce-scatter of pair-symmetric partial sums" if sim.acc_all is not None else "")
                                        + " per step"
                                        + ("" if args.no_overlap or world == 1 else ", all-gather overlapped with the own-slab part")),
