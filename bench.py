@@ -345,6 +345,13 @@ def main():
         kernel_label = ("pair-symmetric tiles + finish" if uses_sym else
                         "one-sided step_wave_kernel" if (world == 1 and prec == nb.FP64 and n <= nb.WAVE_MAX_BODIES
                                                          and args.variant in (0, 7)) else "one-sided step_kernel")
+        # a step may walk the block distances in batches (one launch of the tile kernel each)
+        launches = 1
+        if uses_sym:
+            launches = sim.backend.tile_launches(sim.S, world, sim.count, n, sim.workspace,
+                                                 variant=sim.sym_variant if world > 1 or args.force_collectives else None)
+            if world > 1 or args.force_collectives:
+                launches += 1          # + the diagonal tiles' launch (phase 1)
         line = {
             "metric": "Ginteractions/s at N=1M fp64, 1/2/4/8 MI355X; % of FP64 vector peak",
             "value": round(value, 2), "unit": "Ginteractions/s", "n_gpus": world, "steps": K, "warmup": W,
@@ -359,9 +366,16 @@ def main():
                        "kernel": kernel_label,
                        "kernel_variant": args.variant},
             "roofline": {"bound": "valu_fp64" if prec == nb.FP64 else "valu_fp32", "achieved": round(ach, 3),
-                         "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
+                         "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                         # PMC bytes (profiles/traffic.json holds them per STEP), per launch like `achieved`
+                         "traffic": (round(traffic / launches) if traffic else None), "traffic_per_step": traffic,
                          "kernel": ("sym_tiles_kernel+sym_finish_kernel" if uses_sym else kernel_label.split()[-1]),
-                         "avg_launch_ms": round(dev_s / K * 1e3, 3),
+                         # `achieved` = the step's algorithmic FLOP / the step's device time; a step is
+                         # `launches_per_step` launches of the dominant kernel, each covering that share
+                         "launches_per_step": launches,
+                         "avg_step_ms": round(dev_s / K * 1e3, 3),
+                         "avg_launch_ms": round(dev_s / K / launches * 1e3, 3),
+                         "interactions_per_launch": inter_per_step / world / launches,
                          "flop_per_interaction": FLOP_PER_INTERACTION},
             "pct_of_fp64_vector_peak": round(100 * ach / FP64_VECTOR_PEAK_TFLOPS, 2),
             # the median of the K individually timed steps (HIP events), max over ranks

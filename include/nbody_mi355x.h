@@ -186,6 +186,12 @@ int nbody_mi355x_kdk_drift_f64(const nbody_mi355x_step_args* args, void* stream)
  * kernel, particle_simulation_GPU.cu:60). */
 int nbody_mi355x_step_variant(const nbody_mi355x_step_args* args, int32_t* variant);
 
+/* How many launches of its main (force) kernel a step with these args takes: 1, or -- for the
+ * pair-symmetric kernels with a workspace smaller than the unbatched size -- the number of
+ * batches the block distances are walked in.  For measurement accounting (work per launch =
+ * work per step / launches); read-only, no launch.  No counterpart in the reference. */
+int nbody_mi355x_step_tile_launches(const nbody_mi355x_step_args* args, int32_t* launches);
+
 /* Scratch the pair-symmetric form of the step needs for these args (fields
  * shard_slots, num_shards, variant, precision are read): *bytes = the preferred size --
  * every block distance at once, capped at 4 GiB (or four times the minimum); any size from

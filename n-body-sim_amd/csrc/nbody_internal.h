@@ -43,6 +43,7 @@ bool sym_supported(const nbody_mi355x_step_args& a, int64_t* preferred_bytes, in
 int sym_step(const nbody_mi355x_step_args& a, struct ihipStream_t* stream);
 // the concrete variant (NBODY_MI355X_VARIANT_SYM1 .. SYMW8) the plan for these args resolves to, -1: none
 int sym_resolve(const nbody_mi355x_step_args& a);
+int sym_batches(const nbody_mi355x_step_args& a);
 // nbody_kernels.hip: `substeps` whole small steps of a system of at most kTinyMaxBodies bodies
 // in ONE launch of one wave (in place on a.pos_cur / a.vel; a.snapshot, if set, receives the
 // last small step's records).  One slab, FP64, no split ranges.

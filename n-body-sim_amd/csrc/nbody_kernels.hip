@@ -729,6 +729,21 @@ extern "C" int nbody_mi355x_step_variant(const nbody_mi355x_step_args* args, int
   return NBODY_MI355X_OK;
 }
 
+extern "C" int nbody_mi355x_step_tile_launches(const nbody_mi355x_step_args* args, int32_t* launches) {
+  if (!launches) { set_error("step_tile_launches: null argument"); return NBODY_MI355X_ERR_INVALID; }
+  const int rc = nbody_internal::check_step_args(args);
+  if (rc != NBODY_MI355X_OK) return rc;
+  const int v = resolve_variant(args);
+  *launches = 1;
+  if (v > 0 && is_sym_variant(v)) {
+    nbody_mi355x_step_args a = *args;
+    a.variant = v;
+    const int b = nbody_internal::sym_batches(a);
+    *launches = args->phase == 1 ? 1 : (b > 0 ? b : 1);
+  }
+  return NBODY_MI355X_OK;
+}
+
 extern "C" int nbody_mi355x_step_f64(const nbody_mi355x_step_args* args, void* stream) {
   int rc = nbody_internal::check_step_args(args);
   if (rc != NBODY_MI355X_OK) return rc;

@@ -660,6 +660,24 @@ int sym_resolve(const nbody_mi355x_step_args& a) {
   return (p.wave ? 20 : 10) + p.ipt;  // NBODY_MI355X_VARIANT_SYMW* / _SYM*
 }
 
+// launches of the tile kernel a whole step (phase 0 or 2) takes with this workspace: the
+// iterations of the batch loop in launch(); 0 if the plan or the workspace does not apply
+int sym_batches(const nbody_mi355x_step_args& a) {
+  Plan p;
+  if (!make_plan(a, &p)) return 0;
+  const int64_t fixed = fixed_rows(p, a.num_shards);
+  const int64_t rows = a.workspace ? a.workspace_bytes / p.row_bytes : 0;
+  if (rows < fixed + 1) return 0;
+  int64_t batch = rows - fixed;
+  if (batch > p.D) batch = p.D;
+  int n = 0;
+  for (int64_t lo = a.phase == 2 ? 1 : 0, hi; lo <= p.D; lo = hi + 1, n++) {
+    hi = (lo > 1 ? lo : 1) + batch - 1;
+    if (hi > p.D) hi = p.D;
+  }
+  return n;
+}
+
 int sym_step(const nbody_mi355x_step_args& a, hipStream_t stream) {
   Plan p;
   if (!make_plan(a, &p)) {

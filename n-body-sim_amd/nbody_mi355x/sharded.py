@@ -61,6 +61,20 @@ class HipBackend:
         check(self._lib.nbody_mi355x_step_workspace_bytes(C.byref(a), C.byref(need)))
         return need.value
 
+    def tile_launches(self, S, world, count, n, workspace, variant=None):
+        """Launches of the force kernel per whole step for this layout and workspace (distance batches)."""
+        a = StepArgs()
+        a.pos_cur, a.pos_next, a.mass, a.vel = 8, 16, 8, 8     # (validated, never dereferenced)
+        a.acc_out = 8 if world > 1 else None
+        a.shard_slots, a.num_shards, a.own_shard, a.own_count = S, world, 0, count
+        a.j0_end = n if world == 1 else 0
+        a.precision, a.variant = self.precision, self.variant if variant is None else variant
+        if workspace is not None:
+            a.workspace, a.workspace_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
+        out = C.c_int32(0)
+        check(self._lib.nbody_mi355x_step_tile_launches(C.byref(a), C.byref(out)))
+        return out.value
+
     def step(self, *, pos_cur, pos_next, mass, vel, acc_in, acc_out, snapshot, S, world, rank, count,
              ranges, dt, G, eps2, workspace=None, phase=0, variant=None):
         a = StepArgs()

@@ -193,3 +193,35 @@ def test_header_is_plain_c():
     import subprocess
     subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-fsyntax-only", "-x", "c",
                     str(REPO / "include" / "nbody_mi355x.h")], check=True)
+
+
+def test_step_tile_launches_counts_the_distance_batches():
+    """nbody_mi355x_step_tile_launches: 1 for one-sided / unbatched steps, the number of batches
+    when the workspace holds only part of the block distances (N = 1M with the default 4 GiB
+    workspace: 2 -- bench.py divides the step's work by it for its per-launch figures)."""
+    import ctypes as C
+    L = nb.lib()
+
+    def launches(S, ws_bytes, variant=0):
+        a = nb.StepArgs()
+        a.pos_cur, a.pos_next, a.mass, a.vel = 8, 16, 8, 8
+        a.shard_slots, a.num_shards, a.own_count, a.j0_end, a.variant = S, 1, S, S, variant
+        if ws_bytes:
+            a.workspace, a.workspace_bytes = 8, ws_bytes
+        out = C.c_int32(-1)
+        nb.check(L.nbody_mi355x_step_tile_launches(C.byref(a), C.byref(out)))
+        return out.value
+
+    def preferred(S):
+        a = nb.StepArgs()
+        a.shard_slots, a.num_shards = S, 1
+        need = C.c_int64()
+        nb.check(L.nbody_mi355x_step_workspace_bytes(C.byref(a), C.byref(need)))
+        return need.value
+
+    assert launches(1 << 20, 0) == 1                                  # one-sided
+    assert launches(1 << 20, preferred(1 << 20)) == 2                 # 4 GiB of the 7.3 GB
+    assert launches(1 << 20, 8 << 30) == 1
+    assert launches(65536, preferred(65536)) == 1
+    assert launches(65536, preferred(65536) // 2) >= 2
+    assert launches(1 << 22, preferred(1 << 22)) >= 8
