@@ -442,77 +442,55 @@ double plan_for(const nbody_mi355x_step_args& a, int ipt, Plan* p) {
 // The wave-tile kernels (nbody_symw.hip) with blocks of 64 * ipt slots.  A row's work is the
 // list of its (tile, group) entries -- (D+1) tiles of ipt groups of 64 j bodies -- cut into
 // chunks of `per` entries, one workgroup each, whose 4 waves (all holding the row's bodies)
-// take every fourth entry.  `per` (a multiple of 4 up to 64) is chosen by a small model of
-// the launch, evaluated for every candidate; *model_us receives the winner's estimate, which
-// make_plan compares across block sizes.
-//   * a workgroup of e entries keeps each SIMD of its CU busy for ceil(e / 4) entry times; the
-//     hardware hands workgroups out in blockIdx order (x = rows fastest, so all full chunks
-//     first, the rows' remainder chunks last) to whichever CU has room: nbs * (entries / per)
-//     equal items over 256 CUs take ceil(items / 256) item times, and the remainder chunks
-//     fill the gaps that leaves, or run after;
-//   * every chunk costs one R row (24 bytes per slot) to store and to add again, every
-//     distance one C row: ~9 microseconds per million slots each (measured: 65 536 bodies,
-//     512-body blocks, per = 4 / 8 / 16 / 32 / 64: 1498 / 1476 / 1455 / 1449 / 1450 us).
-// Entry times (64 rotation steps of ipt pairs, microseconds at the ~2.2 GHz the chip holds):
-// 3.4 / 5.7 / 10.8 / 20.7 for ipt = 1 / 2 / 4 / 8 -- the 6 DPP moves and 2 LDS reads of a step
-// are shared by ipt pairs.  Measured on MI355X against the model (us per step, best per):
-// 8192 bodies, 128-body blocks: 39.3; 16 384, 256: 108; 32 768, 512: 379; 65 536, 512: 1420.
-// Sizes that are not powers of two are where the model earns its keep: 12 288 bodies with a
-// fixed per = 16 are 288 full items on 256 CUs -- two rounds for 1.1 rounds' work (97 us).
+// take every fourth entry.  Every chunk costs an R row (24 bytes per slot) to store and to add
+// again, so few large chunks are cheaper -- until the launch stops tiling the chip: the full
+// workgroups are equal items handed to 256 CUs, and a last round that covers only part of them
+// costs a whole round (40 960 bodies, 512-body blocks: per = 8: 579 us, per = 48: 707 us).
+// `per` is chosen from the sweep profiles/r02_wave_tile_sweep.csv (tools/sweep_wave_plan.py: 23
+// sizes x 3 block sizes x 8 values of per):
+//   * where some per makes the number of full workgroups an exact multiple of 256 -- every
+//     power-of-two size, and e.g. 24 576 or 49 152 bodies -- the largest such per that still
+//     leaves two full workgroups per CU wins (16 384: per = 16, 65 536: per = 32 or 64,
+//     131 072: per = 64), else the largest with one per CU;
+//   * otherwise small items level the load: the largest per that still leaves
+//     kWaveMinWorkgroups workgroups (~12 per CU), at least 4.
+// Against the best of the sweep this rule loses 1.5 % on average and 5.5 % at worst; a
+// closed-form model of the rounds (round 2's first attempt) lost 3.5 % and 22 %.
+constexpr int kWaveMinWorkgroups = 3000;
 constexpr int64_t kWaveTileMaxSlots = 262143;  // wave tiles up to here, workgroup tiles beyond
-double plan_wave(const nbody_mi355x_step_args& a, int ipt, Plan* p) {
+bool plan_wave(const nbody_mi355x_step_args& a, int ipt, Plan* p) {
   const int64_t B = 64 * ipt;
-  if (a.num_shards < 1 || a.shard_slots <= 0 || a.shard_slots % B != 0) return -1.0;
-  if (ipt == 8 && a.precision == NBODY_MI355X_FP32 && env_int("NBODY_MI355X_F32_NO8")) return -1.0;  // (A/B tests)
+  if (a.num_shards < 1 || a.shard_slots <= 0 || a.shard_slots % B != 0) return false;
+  if (ipt == 8 && a.precision == NBODY_MI355X_FP32 && env_int("NBODY_MI355X_F32_NO8")) return false;  // (A/B tests)
   p->wave = true;
   p->block = B;
   p->ipt = ipt;
   p->nbs = static_cast<int>(a.shard_slots / B);
   const int64_t nb = static_cast<int64_t>(p->nbs) * a.num_shards;
-  if (nb < 2 || nb > (1 << 24)) return -1.0;
+  if (nb < 2 || nb > (1 << 24)) return false;
   p->nb = static_cast<int>(nb);
   p->D = p->nb / 2;
   const int64_t entries = static_cast<int64_t>(p->D + 1) * ipt;  // per row
-  const double t_entry = ipt == 1 ? 3.4 : (ipt == 2 ? 5.7 : (ipt == 4 ? 10.8 : 20.7));
-  const double t_row = 9e-6 * static_cast<double>(a.shard_slots);  // one R or C row, stored and read back
   constexpr int64_t kCUs = 256;
-  int64_t best_per = 4;
-  double best = -1.0;
-  for (int64_t per = 4; per <= 64; per += 4) {
-    const int64_t full = entries / per, rem = entries % per;
-    const int64_t n_full = p->nbs * full, c_full = per / 4, c_rem = (rem + 3) / 4;
-    const int64_t rounds = (n_full + kCUs - 1) / kCUs, last = n_full % kCUs;
-    double t = static_cast<double>(rounds * c_full);
-    if (rem > 0) {
-      // remainder chunks: into the last round's idle CUs while it runs, the rest after it
-      const int64_t room = (last > 0 && c_rem > 0) ? (kCUs - last) * (c_full / c_rem) : 0;
-      const int64_t left = p->nbs > room ? p->nbs - room : 0;
-      t += static_cast<double>((left + kCUs - 1) / kCUs * c_rem);
-    }
-    const double work = static_cast<double>(p->nbs) * static_cast<double>((entries + 3) / 4) / kCUs;
-    if (t < work) t = work;
-    // a CU that holds a single workgroup at a time (one wave per SIMD) runs it at ~3/4 of the
-    // rate two or more reach between them (measured: 16 384 bodies, 256 workgroups of 8 entries
-    // 102 us, 512 of 4 entries 100 us for half the depth); and every workgroup costs ~2 us of
-    // its own (the row's bodies in, the four waves' sums through LDS, the R row out), hidden
-    // only in part by its CU's other workgroups
-    const int64_t wgs = n_full + (rem > 0 ? p->nbs : 0);
-    const double resident = static_cast<double>(wgs) / kCUs;
-    const double rate = resident >= 2.0 ? 1.0 : (resident <= 1.0 ? 0.75 : 0.75 + 0.25 * (resident - 1.0));
-    const double t_wg = 1.0 * static_cast<double>((wgs + kCUs - 1) / kCUs);
-    t = t * t_entry / rate + t_wg + static_cast<double>(full + (rem > 0 ? 1 : 0)) * t_row;
-    if (best < 0.0 || t < best) {
-      best = t;
-      best_per = per;
-    }
+  int64_t per = 0, per_one = 0;
+  for (int64_t c = 64; c >= 4 && per == 0; c -= 4) {  // an exact tiling of the chip?
+    const int64_t n_full = p->nbs * (entries / c);
+    if (n_full < kCUs || n_full % kCUs != 0) continue;
+    if (n_full >= 2 * kCUs) per = c;
+    else if (per_one == 0) per_one = c;
   }
-  if (const int v = env_int("NBODY_MI355X_SYMW_PER"); v >= 4 && v % 4 == 0) best_per = v;
-  p->per = static_cast<int>(best_per);
-  p->rchunks = static_cast<int>((entries + best_per - 1) / best_per);
+  if (per == 0) per = per_one;
+  if (per == 0) {  // no: small items
+    per = 64;
+    while (per > 4 && static_cast<int64_t>(p->nbs) * ((entries + per - 1) / per) < kWaveMinWorkgroups) per -= 4;
+  }
+  if (const int v = env_int("NBODY_MI355X_SYMW_PER"); v >= 4 && v % 4 == 0) per = v;
+  p->per = static_cast<int>(per);
+  p->rchunks = static_cast<int>((entries + per - 1) / per);
   p->dsplit = p->jsplit = 1;
   p->jlocal = (ipt + 3) / 4;  // phase 1: the ipt entries of the diagonal tile, 4 per workgroup
   plan_bytes(a, p);
-  return best + static_cast<double>(p->D) * t_row;
+  return true;
 }
 
 // The plan is a pure function of (shard_slots, num_shards, variant, precision): the workspace
@@ -522,10 +500,10 @@ bool make_plan(const nbody_mi355x_step_args& a, Plan* p) {
   if (a.variant == NBODY_MI355X_VARIANT_SYM2) return plan_for(a, 2, p) >= 0.0;
   if (a.variant == NBODY_MI355X_VARIANT_SYM4) return plan_for(a, 4, p) >= 0.0;
   if (a.variant == NBODY_MI355X_VARIANT_SYM8) return plan_for(a, 8, p) >= 0.0;
-  if (a.variant == NBODY_MI355X_VARIANT_SYMW1) return plan_wave(a, 1, p) >= 0.0;
-  if (a.variant == NBODY_MI355X_VARIANT_SYMW2) return plan_wave(a, 2, p) >= 0.0;
-  if (a.variant == NBODY_MI355X_VARIANT_SYMW4) return plan_wave(a, 4, p) >= 0.0;
-  if (a.variant == NBODY_MI355X_VARIANT_SYMW8) return plan_wave(a, 8, p) >= 0.0;
+  if (a.variant == NBODY_MI355X_VARIANT_SYMW1) return plan_wave(a, 1, p);
+  if (a.variant == NBODY_MI355X_VARIANT_SYMW2) return plan_wave(a, 2, p);
+  if (a.variant == NBODY_MI355X_VARIANT_SYMW4) return plan_wave(a, 4, p);
+  if (a.variant == NBODY_MI355X_VARIANT_SYMW8) return plan_wave(a, 8, p);
   // automatic.  Up to kWaveTileMaxSlots slots in all: wave tiles, whose work items are small
   // enough to level the load of a short launch; block size by system size.  Measured on
   // MI355X (Ginteractions/s, equal masses; workgroup tiles of the best block in brackets):
@@ -538,19 +516,11 @@ bool make_plan(const nbody_mi355x_step_args& a, Plan* p) {
   {
     const int64_t total = a.shard_slots * a.num_shards;
     if (total <= kWaveTileMaxSlots) {
-      // the block size whose modelled launch is the shortest (64-body blocks: only where no
-      // larger one divides the slab)
-      double best = -1.0;
-      for (int ipt : {8, 4, 2, 1}) {
-        Plan c;
-        const double t = plan_wave(a, ipt, &c);
-        if (t < 0.0 || (ipt == 1 && best >= 0.0)) continue;
-        if (best < 0.0 || t < best) {
-          best = t;
-          *p = c;
-        }
-      }
-      if (best >= 0.0) return true;
+      // block size by system size (sweep: 256-body blocks win up to ~26 000 bodies -- 20 480:
+      // 158 us against 162 with 512 -- and 512-body blocks beyond -- 28 672: 295 against 300);
+      // a smaller block where the larger one does not divide the slab
+      for (int ipt = total < 26624 ? 4 : 8; ipt >= 1; ipt /= 2)
+        if (plan_wave(a, ipt, p)) return true;
     }
   }
   // Beyond: workgroup tiles, the largest block that still leaves enough tiles per rank to keep

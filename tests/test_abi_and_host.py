@@ -147,7 +147,7 @@ def test_step_variant_reports_the_kernel_choice_without_a_gpu():
     big = 1 << 40
     assert variant_of(500) == nb.VARIANT_WAVE and variant_of(nb.WAVE_MAX_BODIES, big) == nb.VARIANT_WAVE
     assert variant_of(100000) in (1, 2) and variant_of(1048576) == 2          # no workspace: one-sided
-    assert variant_of(8192, big) == nb.VARIANT_SYMW2 and variant_of(16384, big) == nb.VARIANT_SYMW4
+    assert variant_of(8192, big) == nb.VARIANT_SYMW4 and variant_of(16384, big) == nb.VARIANT_SYMW4
     assert variant_of(65536, big) == nb.VARIANT_SYMW8 and variant_of(1048576, big) == nb.VARIANT_SYM8
     assert variant_of(65536, big, precision=nb.FP32) == nb.VARIANT_SYMW8 and variant_of(1048576, big, precision=nb.FP32) == nb.VARIANT_SYM8
     assert variant_of(65536, 4096) in (1, 2)                                  # workspace below the minimum

@@ -593,7 +593,7 @@ def test_fp32_symmetric_far_from_the_origin_100_steps(scene):
 
 
 @pytest.mark.parametrize("n,kw,expect", [(2, {}, nb.VARIANT_TINY), (500, {}, nb.VARIANT_WAVE), (4096, {}, nb.VARIANT_WAVE),
-                                         (8192, {}, nb.VARIANT_SYMW2), (65536, {}, nb.VARIANT_SYMW8),
+                                         (8192, {}, nb.VARIANT_SYMW4), (65536, {}, nb.VARIANT_SYMW8),
                                          (300000, {}, nb.VARIANT_SYM8), (300000, {"variant": 2}, 2),
                                          (30000, {"devices": [0, 0]}, nb.VARIANT_SYMW4)])
 def test_kernel_in_use_query(n, kw, expect):

@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""The data behind the launch model of the wave tiles (csrc/nbody_sym.hip: plan_wave): microseconds per
+small step for every (bodies, block = 64 * ipt, entries per workgroup) of a grid, equal masses, FP64.
+    python tools/sweep_wave_plan.py > profiles/r02_wave_tile_sweep.csv"""
+import os
+import sys
+from pathlib import Path
+
+REPO = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(REPO / "n-body-sim_amd"))
+import nbody_mi355x as nb  # noqa: E402
+
+SIZES = [5120, 6144, 7168, 8192, 9216, 10240, 12288, 14336, 16384, 18432, 20480, 24576, 28672, 32768, 36864,
+         40960, 45056, 49152, 57344, 65536, 81920, 98304, 131072]
+PERS = [4, 8, 12, 16, 24, 32, 48, 64]
+print("bodies,ipt,per,us_per_step")
+for n in SIZES:
+    p, m = nb.ic_plummer(n, 42)
+    steps = max(3, min(300, int(1.5e12 / (float(n) * n))))
+    for ipt in (2, 4, 8):
+        for per in PERS:
+            os.environ["NBODY_MI355X_SYMW_PER"] = str(per)
+            try:
+                with nb.Simulation(n, 1e-3, variant=20 + ipt) as sim:
+                    sim.upload(p, m)
+                    sim.run(steps, snapshot=False)
+                    t = []
+                    for _ in range(3):
+                        sim.run(steps, snapshot=False)
+                        t.append(sim.last_run_seconds())
+                print(f"{n},{ipt},{per},{sorted(t)[1] / steps * 1e6:.2f}", flush=True)
+            except nb.NBodyError as e:
+                print(f"# {n},{ipt},{per}: {e}", flush=True)
