@@ -595,7 +595,7 @@ def test_fp32_symmetric_far_from_the_origin_100_steps(scene):
 @pytest.mark.parametrize("n,kw,expect", [(2, {}, nb.VARIANT_TINY), (500, {}, nb.VARIANT_WAVE), (4096, {}, nb.VARIANT_WAVE),
                                          (8192, {}, nb.VARIANT_SYMW4), (65536, {}, nb.VARIANT_SYMW8),
                                          (300000, {}, nb.VARIANT_SYM8), (300000, {"variant": 2}, 2),
-                                         (30000, {"devices": [0, 0]}, nb.VARIANT_SYMW4)])
+                                         (30000, {"devices": [0, 0]}, nb.VARIANT_SYMW8)])
 def test_kernel_in_use_query(n, kw, expect):
     """The handle says which kernel build its small steps run and what workspace it holds
     (nbody_mi355x_kernel_in_use): SimulateMI355X() prints a line when a large system had to
