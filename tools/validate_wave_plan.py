@@ -1,3 +1,8 @@
+#!/usr/bin/env python3
+"""The library's own choice of block size and chunking for the wave tiles (csrc/nbody_sym.hip:
+plan_wave) against six pinned shapes (256- and 512-body blocks x 4 / 8 / 16 entries per workgroup)
+over 39 sizes: microseconds per small step, and how far the choice is from the best of them.
+    python -u tools/validate_wave_plan.py > profiles/r02_wave_tile_validation.txt   (from the repo root)"""
 import os, sys
 sys.path.insert(0, 'n-body-sim_amd')
 import nbody_mi355x as nb
