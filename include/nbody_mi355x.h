@@ -203,6 +203,14 @@ int nbody_mi355x_step_tile_launches(const nbody_mi355x_step_args* args, int32_t*
  * different summation order, bit-reproducible.  No counterpart in the reference. */
 int nbody_mi355x_step_workspace_bytes(const nbody_mi355x_step_args* args, int64_t* bytes);
 
+/* The smallest workspace the same step accepts (one batch of distances at a time), for
+ * callers short of device memory: anything between this and the preferred size works, more
+ * is faster up to the preferred size.  *bytes = 0 where step_workspace_bytes gives 0.
+ * The handles use it themselves: create / create_multi take the preferred size if it is
+ * under half of the free device memory, else what is under half of it down to this
+ * minimum, and only below that run the one-sided kernel.  No counterpart in the reference. */
+int nbody_mi355x_step_workspace_min_bytes(const nbody_mi355x_step_args* args, int64_t* bytes);
+
 /* The same small step for callers that cannot allocate device memory: code under HIP graph
  * capture, tight serving loops, harnesses that forbid hipMalloc.  It has NO counterpart in
  * the reference (whose GPU path allocates per run, particle_simulation_GPU.cu:13-35).  It is
@@ -306,8 +314,8 @@ int nbody_mi355x_energy(nbody_mi355x_sim* sim, double* ke, double* pe);
 /* Which kernel a small step of this handle runs (as nbody_mi355x_step_variant; TINY for the
  * one-launch-per-big-step path) and the pair-symmetric workspace the handle holds, bytes
  * (0: none -- then a system above NBODY_MI355X_WAVE_MAX_BODIES runs a one-sided kernel, at
- * roughly half the rate: create() takes the workspace only if it fits in half of the free
- * device memory).  On a multi-device handle: shard 0's.  No counterpart in the reference. */
+ * roughly half the rate: create() takes a workspace only if at least the kernels' minimum,
+ * nbody_mi355x_step_workspace_min_bytes, fits in half of the free device memory).  On a multi-device handle: shard 0's.  No counterpart in the reference. */
 int nbody_mi355x_kernel_in_use(nbody_mi355x_sim* sim, int32_t* variant, int64_t* workspace_bytes);
 /* Device time (hipEvent) of the kernels of the last nbody_mi355x_run, seconds. */
 int nbody_mi355x_last_run_seconds(nbody_mi355x_sim* sim, double* seconds);

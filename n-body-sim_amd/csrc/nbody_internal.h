@@ -40,6 +40,8 @@ inline int64_t slab_slots(int64_t bodies, int variant) {
 int check_step_args(const nbody_mi355x_step_args* a);
 // nbody_sym.hip: pair-symmetric step (args already validated by check_step_args)
 bool sym_supported(const nbody_mi355x_step_args& a, int64_t* preferred_bytes, int64_t* least_bytes);
+int64_t workspace_budget(size_t free_bytes);
+int64_t workspace_to_take(const nbody_mi355x_step_args& probe, int64_t budget);
 int sym_step(const nbody_mi355x_step_args& a, struct ihipStream_t* stream);
 // the concrete variant (NBODY_MI355X_VARIANT_SYM1 .. SYMW8) the plan for these args resolves to, -1: none
 int sym_resolve(const nbody_mi355x_step_args& a);

@@ -791,6 +791,38 @@ extern "C" int nbody_mi355x_step_workspace_bytes(const nbody_mi355x_step_args* a
   return NBODY_MI355X_OK;
 }
 
+extern "C" int nbody_mi355x_step_workspace_min_bytes(const nbody_mi355x_step_args* args, int64_t* bytes) {
+  if (!args || !bytes) { set_error("step_workspace_min_bytes: null argument"); return NBODY_MI355X_ERR_INVALID; }
+  int64_t pref = 0, least = 0;
+  nbody_mi355x_step_args a = *args;
+  if (!is_sym_variant(a.variant)) a.variant = NBODY_MI355X_VARIANT_SYM;
+  *bytes = nbody_internal::sym_supported(a, &pref, &least) ? least : 0;
+  return NBODY_MI355X_OK;
+}
+
+namespace nbody_internal {
+// What a handle takes for the symmetric kernels out of `budget` bytes: the preferred size if
+// it fits, else the budget itself down to the minimum, else 0 (one-sided kernel).
+// Half of the free device memory; NBODY_MI355X_WS_BUDGET_MB lowers it (a way to leave room
+// for what the caller allocates after the handle -- and how the tests stand in for a full GPU).
+int64_t workspace_budget(size_t free_bytes) {
+  int64_t budget = static_cast<int64_t>(free_bytes / 2);
+  if (const char* e = getenv("NBODY_MI355X_WS_BUDGET_MB")) {
+    const long long mb = atoll(e);
+    if (mb >= 0 && (mb << 20) < budget) budget = mb << 20;
+  }
+  return budget;
+}
+
+int64_t workspace_to_take(const nbody_mi355x_step_args& probe, int64_t budget) {
+  int64_t pref = 0, least = 0;
+  if (nbody_mi355x_step_workspace_bytes(&probe, &pref) != NBODY_MI355X_OK || pref <= 0) return 0;
+  if (nbody_mi355x_step_workspace_min_bytes(&probe, &least) != NBODY_MI355X_OK || least <= 0) return 0;
+  if (pref <= budget) return pref;
+  return least <= budget ? budget : 0;
+}
+}  // namespace nbody_internal
+
 extern "C" int nbody_mi355x_pack_f64(const double* aos, int64_t count, double* pos_slab, double* vel,
                                      int64_t shard_slots, void* stream) {
   if (!aos || !pos_slab || !vel || count < 0 || count > shard_slots) {

@@ -464,11 +464,15 @@ int multi_create(const nbody_mi355x_config& cfg, const int32_t* devices, int32_t
   for (int r = 0; r < num && m->sym; r++) {
     Shard& s = m->sh[r];
     size_t free_b = 0, total_b = 0;
-    const bool fits = hipSetDevice(s.device) == hipSuccess && hipMemGetInfo(&free_b, &total_b) == hipSuccess &&
-                      static_cast<size_t>(need) + 2 * all < free_b / 2;
-    if (fits && hipMalloc(&s.acc_all, all) == hipSuccess && hipMalloc(&s.stage, all) == hipSuccess &&
-        hipMalloc(&s.workspace, static_cast<size_t>(need)) == hipSuccess) {
-      s.workspace_bytes = need;
+    // the preferred workspace, or what is left of half the free memory down to the minimum
+    int64_t take = 0;
+    if (hipSetDevice(s.device) == hipSuccess && hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+      const int64_t budget = nbody_internal::workspace_budget(free_b) - 2 * static_cast<int64_t>(all);
+      take = budget > 0 ? nbody_internal::workspace_to_take(probe, budget) : 0;
+    }
+    if (take > 0 && hipMalloc(&s.acc_all, all) == hipSuccess && hipMalloc(&s.stage, all) == hipSuccess &&
+        hipMalloc(&s.workspace, static_cast<size_t>(take)) == hipSuccess) {
+      s.workspace_bytes = take;
       continue;
     }
     (void)hipGetLastError();

@@ -167,8 +167,9 @@ extern "C" int nbody_mi355x_create(const nbody_mi355x_config* cfg, nbody_mi355x_
     set_error("create: device allocation failed for N=%lld", (long long)cfg->num_particles);
     return NBODY_MI355X_ERR_ALLOC;
   }
-  // Workspace of the symmetric kernels: taken only if it fits comfortably (it grows as
-  // N^2 / 1024); without it the one-sided kernel runs, same results to rounding.
+  // Workspace of the symmetric kernels: the preferred size if that is under half of the free
+  // memory, else what is under half of it down to the kernels' minimum (they then walk the
+  // distances in more batches); without one the one-sided kernel runs, same results to rounding.
   {
     nbody_mi355x_step_args probe;
     memset(&probe, 0, sizeof probe);
@@ -176,15 +177,15 @@ extern "C" int nbody_mi355x_create(const nbody_mi355x_config* cfg, nbody_mi355x_
     probe.num_shards = 1;
     probe.variant = cfg->variant;
     probe.precision = cfg->precision;
-    int64_t need = 0;
     size_t free_b = 0, total_b = 0;
     // (small systems run the wave-per-body kernels by default: no workspace to hold)
     const bool wanted = (cfg->variant == 0 && s->n > NBODY_MI355X_WAVE_MAX_BODIES) ||
                         nbody_internal::is_sym_variant(cfg->variant);
-    if (wanted && nbody_mi355x_step_workspace_bytes(&probe, &need) == NBODY_MI355X_OK && need > 0 &&
-        hipMemGetInfo(&free_b, &total_b) == hipSuccess && static_cast<size_t>(need) < free_b / 2 &&
-        hipMalloc(&s->workspace, static_cast<size_t>(need)) == hipSuccess) {
-      s->workspace_bytes = need;
+    int64_t take = 0;
+    if (wanted && hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+      take = nbody_internal::workspace_to_take(probe, nbody_internal::workspace_budget(free_b));
+    if (take > 0 && hipMalloc(&s->workspace, static_cast<size_t>(take)) == hipSuccess) {
+      s->workspace_bytes = take;
     } else {
       (void)hipGetLastError();
       s->workspace = nullptr;

@@ -83,6 +83,7 @@ SYMBOLS = {
     "nbody_mi355x_step_tile_launches": (C.c_int, [C.POINTER(StepArgs), C.POINTER(C.c_int32)]),
     "nbody_mi355x_step_variant": (C.c_int, [C.POINTER(StepArgs), C.POINTER(C.c_int32)]),
     "nbody_mi355x_step_workspace_bytes": (C.c_int, [C.POINTER(StepArgs), C.POINTER(C.c_int64)]),
+    "nbody_mi355x_step_workspace_min_bytes": (C.c_int, [C.POINTER(StepArgs), C.POINTER(C.c_int64)]),
     "nbody_mi355x_pack_f64": (C.c_int, [_P, C.c_int64, _P, _P, C.c_int64, _P]),
     "nbody_mi355x_unpack_f64": (C.c_int, [_P, _P, C.c_int64, C.c_int64, _P, _P]),
     "nbody_mi355x_energy_f64": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int64,

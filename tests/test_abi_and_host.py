@@ -180,8 +180,16 @@ def test_launch_plans_exist_and_are_consistent_for_every_layout():
                 assert need.value > 0, (S, shards, prec)
                 assert need.value % (24 * S) == 0                     # whole rows of 3*S doubles
                 assert need.value <= max(4 << 30, 4 * 24 * S * 80)    # capped (80 rows: a generous bound on the minimum)
+                least = C.c_int64(-1)
+                nb.check(L.nbody_mi355x_step_workspace_min_bytes(C.byref(a), C.byref(least)))
+                assert 0 < least.value <= need.value and least.value % (24 * S) == 0
+                vmin = C.c_int32(-1)
+                a.workspace, a.workspace_bytes = 8, least.value       # the minimum is accepted ...
+                nb.check(L.nbody_mi355x_step_variant(C.byref(a), C.byref(vmin)))
+                assert vmin.value in nb.SYM_VARIANTS, (S, shards, prec, vmin.value)
                 a.workspace, a.workspace_bytes = 8, need.value
                 nb.check(L.nbody_mi355x_step_variant(C.byref(a), C.byref(v)))
+                assert vmin.value == v.value                          # ... by the same kernel build
                 assert v.value in nb.SYM_VARIANTS and v.value != nb.VARIANT_SYM, (S, shards, prec, v.value)
                 block = {11: 256, 12: 512, 14: 1024, 18: 2048, 21: 64, 22: 128, 24: 256, 28: 512}[v.value]
                 assert S % block == 0 and total // block >= 2

@@ -751,6 +751,39 @@ def test_small_workspace_cap_batches_the_distances(monkeypatch):
     assert vec_rel(out[:, 6:9], ref[0, :, 6:9]) <= 1e-12
 
 
+def test_handle_shrinks_its_workspace_before_giving_up_the_symmetric_kernels(monkeypatch):
+    """A GPU short of free memory: create takes what is under half of the free memory, down to
+    the kernels' minimum, and only below that falls back to the one-sided kernel (half the
+    rate).  NBODY_MI355X_WS_BUDGET_MB stands in for the full GPU."""
+    import ctypes as C
+    n = 40000
+    p, m = nb.ic_plummer(n, 23)
+    a = nb.StepArgs()
+    a.shard_slots, a.num_shards = 40960, 1
+    pref, least = C.c_int64(), C.c_int64()
+    nb.check(nb.lib().nbody_mi355x_step_workspace_bytes(C.byref(a), C.byref(pref)))
+    nb.check(nb.lib().nbody_mi355x_step_workspace_min_bytes(C.byref(a), C.byref(least)))
+    assert 0 < least.value < pref.value
+    between = (least.value >> 20) + 2
+    assert (between << 20) < pref.value
+    monkeypatch.setenv("NBODY_MI355X_WS_BUDGET_MB", str(between))
+    with nb.Simulation(n, 1e-3) as sim:
+        variant, held = sim.kernel_in_use()
+        sim.upload(p, m)
+        out = sim.run(2, snapshot=True)
+    assert variant in nb.SYM_VARIANTS and least.value <= held <= between << 20
+    _, ref = ol.simulate(p, m, 1, 2, 1e-3, threads=16)
+    assert rel_pos_err(out[:, :3], ref[0, :, :3]) <= 1e-14
+    assert vec_rel(out[:, 6:9], ref[0, :, 6:9]) <= 1e-12
+    monkeypatch.setenv("NBODY_MI355X_WS_BUDGET_MB", str(max((least.value >> 20) - 1, 0)))
+    with nb.Simulation(n, 1e-3) as sim:
+        variant, held = sim.kernel_in_use()
+        sim.upload(p, m)
+        one = sim.run(2, snapshot=True)
+    assert variant not in nb.SYM_VARIANTS and held == 0
+    assert rel_pos_err(one[:, :3], ref[0, :, :3]) <= 1e-14
+
+
 @pytest.mark.parametrize("n,kw", [(300, {}), (5000, {})])
 def test_kdk_through_graph_replay(n, kw):
     """Many leapfrog small steps of a small system: the fused {kick, kick, drift} steps are
