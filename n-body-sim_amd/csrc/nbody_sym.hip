@@ -113,26 +113,25 @@ __global__ __launch_bounds__(256) void sym_tiles_kernel(const SymArgs a) {
   const int g0 = blockIdx.z * ng;             // ... starting here (64 bodies per group)
   const int I = a.row0 + il;
   const int64_t S = a.S;
-  // double: 2^-300 stands in for "no softening" (nbody_device.hpp); float: plain 0 + a select
-  const T eps2 = static_cast<T>((a.eps2 > 0.0) ? a.eps2 : (sizeof(T) == sizeof(double) ? kTinyR2 : 0.0));
   T c15 = static_cast<T>(1.5), c1875 = static_cast<T>(1.875);
   asm volatile("" : "+v"(c15), "+v"(c1875));
 
   T xi[IPT], yi[IPT], zi[IPT], mi[IPT], ax[IPT], ay[IPT], az[IPT];
   // float only: the origin the row's and the staged bodies' coordinates are taken relative
-  // to BEFORE they are narrowed (row_origin); 0 in double, where nothing is subtracted
-  double ox = 0.0, oy = 0.0, oz = 0.0;
+  // to, and the power of two they are multiplied by, BEFORE they are narrowed (row_origin);
+  // 0 and 1 in double, where nothing is subtracted or scaled
+  double ox = 0.0, oy = 0.0, oz = 0.0, sc = 1.0;
   {
     const double *px, *pm;
     block_base<B>(a, I, &px, &pm);
-    if constexpr (sizeof(T) == sizeof(float)) row_origin<IPT>(px, pm, S, tid, &ox, &oy, &oz);
+    if constexpr (sizeof(T) == sizeof(float)) row_origin<IPT>(px, pm, S, tid, &ox, &oy, &oz, &sc);
 #pragma unroll
     for (int k = 0; k < IPT; k++) {
       const int idx = k * 256 + tid;
       if constexpr (sizeof(T) == sizeof(float)) {
-        xi[k] = static_cast<T>(px[idx] - ox);
-        yi[k] = static_cast<T>(px[S + idx] - oy);
-        zi[k] = static_cast<T>(px[2 * S + idx] - oz);
+        xi[k] = static_cast<T>((px[idx] - ox) * sc);
+        yi[k] = static_cast<T>((px[S + idx] - oy) * sc);
+        zi[k] = static_cast<T>((px[2 * S + idx] - oz) * sc);
       } else {
         xi[k] = static_cast<T>(px[idx]);
         yi[k] = static_cast<T>(px[S + idx]);
@@ -142,6 +141,9 @@ __global__ __launch_bounds__(256) void sym_tiles_kernel(const SymArgs a) {
       ax[k] = ay[k] = az[k] = 0;
     }
   }
+  // double: 2^-300 stands in for "no softening" (nbody_device.hpp); float: plain 0 + a select
+  // (or, softened, eps2 in the row's scaled units)
+  const T eps2 = static_cast<T>((a.eps2 > 0.0) ? a.eps2 * sc * sc : (sizeof(T) == sizeof(double) ? kTinyR2 : 0.0));
   // do all bodies of this row have one (finite, non-zero) mass?  Workgroup-uniform answer.
   __shared__ T m_row;
   if (tid == 0) m_row = mi[0];
@@ -156,6 +158,12 @@ __global__ __launch_bounds__(256) void sym_tiles_kernel(const SymArgs a) {
   // double: a uniform row keeps its i sums in units of 1/m_ref (kDeferred / kRowUnit)
   constexpr bool kDouble = sizeof(T) == sizeof(double);
   const T inv_m_ref = row_uniform ? inv_probe : 0;
+  // float: a uniform row's i sums are in units of its mass AND of the scale: staged masses
+  // are divided by m_ref (so the general form's m_j r^-3 lands in the same unit), and the
+  // sums are converted when they are stored, in double
+  const double m_unit = (!kDouble && row_uniform) ? static_cast<double>(m_ref) : 1.0;
+  const double stage_m = 1.0 / m_unit;
+  const double unit_i = sc * sc * m_unit;
 
   // distances [d_lo, d_hi] cut into dsplit chunks whose sizes differ by at most one
   const int nd = a.d_hi - a.d_lo + 1;
@@ -182,13 +190,13 @@ __global__ __launch_bounds__(256) void sym_tiles_kernel(const SymArgs a) {
         const int e = o & 63, q = (o >> 6) * kGrp + e;
         P2<T> vxy, vzm;
         if constexpr (sizeof(T) == sizeof(float)) {  // relative to the row's origin, narrowed after
-          vxy = P2<T>{static_cast<T>(px[idx] - ox), static_cast<T>(px[S + idx] - oy)};
-          vzm = P2<T>{static_cast<T>(px[2 * S + idx] - oz), static_cast<T>(pm[idx])};
+          vxy = P2<T>{static_cast<T>((px[idx] - ox) * sc), static_cast<T>((px[S + idx] - oy) * sc)};
+          vzm = P2<T>{static_cast<T>((px[2 * S + idx] - oz) * sc), static_cast<T>(pm[idx] * stage_m)};
         } else {
           vxy = P2<T>{static_cast<T>(px[idx]), static_cast<T>(px[S + idx])};
           vzm = P2<T>{static_cast<T>(px[2 * S + idx]), static_cast<T>(pm[idx])};
         }
-        fill_same = fill_same && (vzm.b == m_ref);
+        fill_same = fill_same && (static_cast<T>(pm[idx]) == m_ref);
         xy[q] = vxy;
         zm[q] = vzm;
         fJ[0][q] = 0;
@@ -212,12 +220,20 @@ __global__ __launch_bounds__(256) void sym_tiles_kernel(const SymArgs a) {
           if (equal_mass) NBODY_TILE(true, kSameMass);
           else NBODY_TILE(true, kGeneral);
         }
+        // float: out of the scaled units (of the common mass too where the fill had one)
+        const double unit_j = kDouble ? 1.0 : sc * sc * (equal_mass ? static_cast<double>(m_ref) : 1.0);
         for (int o = tid; o < j_n; o += 256) {
           const int idx = j_lo + o;
           const int q = (o >> 6) * kGrp + (o & 63);
-          Cd[idx] = fJ[0][q];
-          Cd[S + idx] = fJ[1][q];
-          Cd[2 * S + idx] = fJ[2][q];
+          if constexpr (kDouble) {
+            Cd[idx] = fJ[0][q];
+            Cd[S + idx] = fJ[1][q];
+            Cd[2 * S + idx] = fJ[2][q];
+          } else {
+            Cd[idx] = fJ[0][q] * unit_j;
+            Cd[S + idx] = fJ[1][q] * unit_j;
+            Cd[2 * S + idx] = fJ[2][q] * unit_j;
+          }
         }
       } else {  // the diagonal tile (1 of nb/2 + 1): no form of its own for equal masses
         if (kDouble && row_uniform) NBODY_TILE(false, kRowUnit);
@@ -237,9 +253,15 @@ __global__ __launch_bounds__(256) void sym_tiles_kernel(const SymArgs a) {
       ay[k] *= m_ref;
       az[k] *= m_ref;
     }
-    Rs[idx] = ax[k];
-    Rs[S + idx] = ay[k];
-    Rs[2 * S + idx] = az[k];
+    if constexpr (kDouble) {
+      Rs[idx] = ax[k];
+      Rs[S + idx] = ay[k];
+      Rs[2 * S + idx] = az[k];
+    } else {
+      Rs[idx] = ax[k] * unit_i;
+      Rs[S + idx] = ay[k] * unit_i;
+      Rs[2 * S + idx] = az[k] * unit_i;
+    }
   }
 }
 

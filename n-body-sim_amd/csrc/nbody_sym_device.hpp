@@ -119,6 +119,161 @@ constexpr int kGrp = 72;
 // results agree to an ulp or two of each sum, not bit for bit.
 enum { kGeneral = 0, kDeferred = 1, kRowUnit = 2, kSameMass = 3 };
 
+// The FP32 walk with PACKED arithmetic: two of the lane's bodies per instruction.
+// Measured on gfx950 (tools/ubench/valu_rates.hip, ns per wave instruction per SIMD):
+// v_fma_f32 1.6, v_pk_fma_f32 2.0 for two FMAs; v_mul/v_sub_f32 1.1, v_pk_mul/v_pk_add_f32
+// 1.9 for two -- the 9 FMAs of a pair are what packing pays for.  The j body arrives from LDS
+// as two 64-bit pairs {x,y} {z,m}, and a packed instruction can take either half of a pair
+// for both of its lanes (op_sel), so broadcasting x_j, y_j, z_j, m_j costs nothing; the
+// compiler folds the splats below into op_sel (checked in the ISA: no v_mov in the loop).
+// The j-side sums travel as TWO partial sums per component (even / odd bodies of the lane),
+// added when they are home.  Element for element the operations are the scalar path's
+// (IEEE fma / mul / add), in the same order on the i side.
+// SOFT: eps2 >= FLT_MIN, so r^2 > 0 for every pair and nothing has to be done about r^2 == 0.
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f2 splat(float v) { return f2{v, v}; }
+
+// ZERO: what is done about r^2 == 0 (a body met with itself, or two in one place), which must
+// give no force:
+//   kZeroNone    nothing -- softened (eps2 >= FLT_MIN), r^2 > 0 for every pair;
+//   kZeroSelect  such a pair's r^2 becomes +inf, whose rsq is 0: 2 instructions a pair;
+//   kZeroTrack   nothing, but the smallest r^2 seen is handed back (one v_min3 per two
+//                pairs): the caller discards the walk's sums and walks again with kZeroSelect
+//                if it was 0.  Off the diagonal tile that takes two bodies in one place.
+enum { kZeroNone = 0, kZeroSelect = 1, kZeroTrack = 2 };
+
+template <int H, bool SYM, int MODE, int ZERO>
+__device__ __forceinline__ void walk_pk(const P2<float>* xy, const P2<float>* zm, int gb, int lane,
+                                        const f2 (&xi2)[H], const f2 (&yi2)[H], const f2 (&zi2)[H],
+                                        const f2 (&mi2)[H], f2 (&ax2)[H], f2 (&ay2)[H], f2 (&az2)[H], f2 e2,
+                                        f2* fxo, f2* fyo, f2* fzo, float* least_o) {
+  // W packed pairs go through each stage together: neighbours in the instruction stream are
+  // then independent (a packed result is not ready for the very next instruction), at W
+  // times the live temporaries
+  constexpr int W = H >= 2 ? 2 : 1;
+  f2 fx = {0, 0}, fy = {0, 0}, fz = {0, 0};
+  float least = __builtin_inff();
+  int rot = lane;
+  P2<float> bxy[2], bzm[2];
+  bxy[0] = xy[gb + rot];
+  bzm[0] = zm[gb + rot];
+  for (int t8 = 0; t8 < 8; t8++) {
+    const int rot_next = (rot + 8) & 63;
+    const P2<float>* pxy = xy + gb + rot;
+    const P2<float>* pzm = zm + gb + rot;
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      bxy[(u + 1) & 1] = u < 7 ? pxy[u + 1] : xy[gb + rot_next];
+      bzm[(u + 1) & 1] = u < 7 ? pzm[u + 1] : zm[gb + rot_next];
+      const f2 jxy = __builtin_bit_cast(f2, bxy[u & 1]);
+      const f2 jzm = __builtin_bit_cast(f2, bzm[u & 1]);
+#pragma unroll
+      for (int k0 = 0; k0 < H; k0 += W) {
+        f2 dx[W], dy[W], dz[W], r2[W], y0[W], si[W], sj[W];
+#pragma unroll
+        for (int k = 0; k < W; k++) {
+          dx[k] = splat(jxy.x) - xi2[k0 + k];
+          dy[k] = splat(jxy.y) - yi2[k0 + k];
+          dz[k] = splat(jzm.x) - zi2[k0 + k];
+        }
+#pragma unroll
+        for (int k = 0; k < W; k++) r2[k] = fma2(dx[k], dx[k], e2);
+#pragma unroll
+        for (int k = 0; k < W; k++) r2[k] = fma2(dy[k], dy[k], r2[k]);
+#pragma unroll
+        for (int k = 0; k < W; k++) r2[k] = fma2(dz[k], dz[k], r2[k]);
+#pragma unroll
+        for (int k = 0; k < W; k++) {
+          if (ZERO == kZeroSelect) {
+            r2[k].x = (r2[k].x > 0.0f) ? r2[k].x : __builtin_inff();
+            r2[k].y = (r2[k].y > 0.0f) ? r2[k].y : __builtin_inff();
+          }
+          if (ZERO == kZeroTrack) least = __builtin_fminf(__builtin_fminf(least, r2[k].x), r2[k].y);
+          y0[k] = f2{__builtin_amdgcn_rsqf(r2[k].x), __builtin_amdgcn_rsqf(r2[k].y)};
+        }
+#pragma unroll
+        for (int k = 0; k < W; k++) {
+          const f2 y3 = (y0[k] * y0[k]) * y0[k];  // (scaled coordinates: O(1), see pow2_scale)
+          if (MODE == kSameMass) {
+            si[k] = sj[k] = y3;
+          } else {
+            si[k] = splat(jzm.y) * y3;
+            if (SYM) sj[k] = mi2[k0 + k] * y3;
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < W; k++) {
+          ax2[k0 + k] = fma2(si[k], dx[k], ax2[k0 + k]);
+          ay2[k0 + k] = fma2(si[k], dy[k], ay2[k0 + k]);
+          az2[k0 + k] = fma2(si[k], dz[k], az2[k0 + k]);
+        }
+        if (SYM) {
+#pragma unroll
+          for (int k = 0; k < W; k++) {
+            fx = fma2(-sj[k], dx[k], fx);
+            fy = fma2(-sj[k], dy[k], fy);
+            fz = fma2(-sj[k], dz[k], fz);
+          }
+        }
+      }
+      if (SYM) {  // both partial sums follow their body
+        fx = f2{rotate_from_next_lane(fx.x), rotate_from_next_lane(fx.y)};
+        fy = f2{rotate_from_next_lane(fy.x), rotate_from_next_lane(fy.y)};
+        fz = f2{rotate_from_next_lane(fz.x), rotate_from_next_lane(fz.y)};
+      }
+    }
+    rot = rot_next;
+  }
+  *fxo = fx;
+  *fyo = fy;
+  *fzo = fz;
+  *least_o = least;
+}
+
+template <int IPT, bool SYM, int MODE, bool SOFT>
+__device__ __forceinline__ void group_steps_pk(const P2<float>* xy, const P2<float>* zm, int gb, int lane,
+                                               const float (&xi)[IPT], const float (&yi)[IPT],
+                                               const float (&zi)[IPT], const float (&mi)[IPT], float (&ax)[IPT],
+                                               float (&ay)[IPT], float (&az)[IPT], float eps2, float* fxo,
+                                               float* fyo, float* fzo) {
+  static_assert(IPT % 2 == 0, "two bodies per packed instruction");
+  static_assert(MODE == kGeneral || MODE == kSameMass, "the float forms");
+  constexpr int H = IPT / 2;
+  f2 xi2[H], yi2[H], zi2[H], mi2[H], gx[H], gy[H], gz[H];
+#pragma unroll
+  for (int k = 0; k < H; k++) {
+    xi2[k] = f2{xi[2 * k], xi[2 * k + 1]};
+    yi2[k] = f2{yi[2 * k], yi[2 * k + 1]};
+    zi2[k] = f2{zi[2 * k], zi[2 * k + 1]};
+    mi2[k] = f2{mi[2 * k], mi[2 * k + 1]};
+    gx[k] = gy[k] = gz[k] = f2{0, 0};  // this group's share of the i-side sums
+  }
+  const f2 e2 = splat(eps2);
+  f2 fx, fy, fz;
+  float least;
+  // the diagonal tile meets every body with itself: selects from the start
+  constexpr int kFirst = SOFT ? kZeroNone : (SYM ? kZeroTrack : kZeroSelect);
+  walk_pk<H, SYM, MODE, kFirst>(xy, zm, gb, lane, xi2, yi2, zi2, mi2, gx, gy, gz, e2, &fx, &fy, &fz, &least);
+  if constexpr (kFirst == kZeroTrack) {
+    if (__builtin_expect(__any(!(least > 0.0f)), 0)) {  // (also: a NaN in the walk's r^2 ... stays one)
+#pragma unroll
+      for (int k = 0; k < H; k++) gx[k] = gy[k] = gz[k] = f2{0, 0};
+      walk_pk<H, SYM, MODE, kZeroSelect>(xy, zm, gb, lane, xi2, yi2, zi2, mi2, gx, gy, gz, e2, &fx, &fy, &fz,
+                                         &least);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < H; k++) {
+    ax[2 * k] += gx[k].x; ax[2 * k + 1] += gx[k].y;
+    ay[2 * k] += gy[k].x; ay[2 * k + 1] += gy[k].y;
+    az[2 * k] += gz[k].x; az[2 * k + 1] += gz[k].y;
+  }
+  *fxo = fx.x + fx.y;
+  *fyo = fy.x + fy.y;
+  *fzo = fz.x + fz.y;
+}
+
 // One group of 64 j bodies (LDS entries gb .. gb+71) against this wave's 64*IPT bodies: at
 // step t the lane meets body (lane + t) mod 64 of the group.  SYM: the j-side sums travel
 // with their body through the lanes, one DPP wave rotation per step (6 v_mov_b32_dpp, 3.3
@@ -132,6 +287,14 @@ __device__ __forceinline__ void group_steps(const P2<T>* xy, const P2<T>* zm, in
                                             const T (&yi)[IPT], const T (&zi)[IPT], const T (&mi)[IPT],
                                             T (&ax)[IPT], T (&ay)[IPT], T (&az)[IPT], T eps2, T c15, T c1875,
                                             T inv_m_ref, T* fxo, T* fyo, T* fzo) {
+  if constexpr (sizeof(T) == sizeof(float) && IPT % 2 == 0 && (MODE == kGeneral || MODE == kSameMass)) {  // FP32: packed
+    if (eps2 >= 1.17549435e-38f) {
+      group_steps_pk<IPT, SYM, MODE, true>(xy, zm, gb, lane, xi, yi, zi, mi, ax, ay, az, eps2, fxo, fyo, fzo);
+    } else {
+      group_steps_pk<IPT, SYM, MODE, false>(xy, zm, gb, lane, xi, yi, zi, mi, ax, ay, az, eps2, fxo, fyo, fzo);
+    }
+    return;
+  }
   T fx = 0, fy = 0, fz = 0;
   int rot = lane;
   // the body of the NEXT step is read while this step's pairs are evaluated: two register
@@ -213,10 +376,30 @@ __device__ __forceinline__ double uniform(double v) {  // a wave-uniform value i
   return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)),
                           __builtin_amdgcn_readfirstlane(__double2loint(v)));
 }
+// ... and the SCALE they are measured in: a power of two c (exact in double and float) that
+// brings the row's extent -- the largest |coordinate - origin| of its real bodies -- into
+// [1, 2).  In scaled coordinates r'^-3 = (c r)^-3 is O(1) for the pairs that matter, so the
+// bare cube can be formed in float (unscaled, r^-3 leaves float's range beyond r = 4e12 --
+// metres to Neptune) and the masses stay out of the pair: sums are in units of c^2 (and of
+// the common mass, where there is one) and are converted once, in double, when stored.
+// 1 for a row without extent, or with one that is not finite.
+__device__ __forceinline__ double pow2_scale(double ext) {
+  int e = ((__double2hiint(ext) >> 20) & 0x7ff) - 1023;
+  if (!(ext > 0.0) || e == 1024 || e == -1023) return 1.0;  // 0, NaN, inf, subnormal
+  e = e > 500 ? 500 : (e < -500 ? -500 : e);                // c * c must stay a double
+  return __hiloint2double((1023 - e) << 20, 0);
+}
+__device__ __forceinline__ double body_extent(double x, double y, double z, double m, double ox, double oy,
+                                              double oz) {
+  const bool padding = m == 0.0 && x == 0.0 && y == 0.0 && z == 0.0;
+  const double ex = __builtin_fabs(x - ox), ey = __builtin_fabs(y - oy), ez = __builtin_fabs(z - oz);
+  const double e = __builtin_fmax(ex, __builtin_fmax(ey, ez));
+  return (padding || !(e - e == 0.0)) ? 0.0 : e;  // padding and non-finite bodies do not set the scale
+}
 template <int IPT>
 __device__ __forceinline__ void row_origin(const double* px, const double* pm, int64_t S, int tid, double* ox,
-                                           double* oy, double* oz) {
-  __shared__ double cen[4][4];
+                                           double* oy, double* oz, double* scale) {
+  __shared__ double cen[4][5];
   double sx = 0.0, sy = 0.0, sz = 0.0, cnt = 0.0;
 #pragma unroll
   for (int k = 0; k < IPT; k++) {
@@ -237,15 +420,29 @@ __device__ __forceinline__ void row_origin(const double* px, const double* pm, i
   }
   __syncthreads();
   const double n = cen[0][3] + cen[1][3] + cen[2][3] + cen[3][3];
-  const double cx = (cen[0][0] + cen[1][0] + cen[2][0] + cen[3][0]) / n;
-  const double cy = (cen[0][1] + cen[1][1] + cen[2][1] + cen[3][1]) / n;
-  const double cz = (cen[0][2] + cen[1][2] + cen[2][2] + cen[3][2]) / n;
+  double cx = (cen[0][0] + cen[1][0] + cen[2][0] + cen[3][0]) / n;
+  double cy = (cen[0][1] + cen[1][1] + cen[2][1] + cen[3][1]) / n;
+  double cz = (cen[0][2] + cen[1][2] + cen[2][2] + cen[3][2]) / n;
   const bool ok = n > 0.0 && (cx - cx == 0.0) && (cy - cy == 0.0) && (cz - cz == 0.0);
   // workgroup-uniform: kept in scalar registers (the float IPT = 4 build sits at the VGPR
   // count that still allows two waves per SIMD; six more VGPRs halve its occupancy)
-  *ox = uniform(ok ? cx : 0.0);
-  *oy = uniform(ok ? cy : 0.0);
-  *oz = uniform(ok ? cz : 0.0);
+  cx = uniform(ok ? cx : 0.0);
+  cy = uniform(ok ? cy : 0.0);
+  cz = uniform(ok ? cz : 0.0);
+  double ext = 0.0;
+#pragma unroll
+  for (int k = 0; k < IPT; k++) {
+    const int idx = k * 256 + tid;
+    ext = __builtin_fmax(ext, body_extent(px[idx], px[S + idx], px[2 * S + idx], pm[idx], cx, cy, cz));
+  }
+  for (int o = 32; o > 0; o >>= 1) ext = __builtin_fmax(ext, __shfl_down(ext, o, 64));
+  if ((tid & 63) == 0) cen[tid >> 6][4] = ext;
+  __syncthreads();
+  ext = __builtin_fmax(__builtin_fmax(cen[0][4], cen[1][4]), __builtin_fmax(cen[2][4], cen[3][4]));
+  *ox = cx;
+  *oy = cy;
+  *oz = cz;
+  *scale = uniform(pow2_scale(ext));
 }
 
 

@@ -36,7 +36,7 @@ namespace {
 // here every wave holds the whole row, so the sum is a wave reduction and needs no LDS.
 template <int IPT>
 __device__ __forceinline__ void wave_origin(const double* px, const double* pm, int64_t S, int lane, double* ox,
-                                            double* oy, double* oz) {
+                                            double* oy, double* oz, double* scale) {
   double sx = 0.0, sy = 0.0, sz = 0.0, cnt = 0.0;
 #pragma unroll
   for (int k = 0; k < IPT; k++) {
@@ -53,11 +53,22 @@ __device__ __forceinline__ void wave_origin(const double* px, const double* pm, 
     cnt += __shfl_down(cnt, o, 64);
   }
   const double n = uniform(cnt);
-  const double cx = uniform(sx) / n, cy = uniform(sy) / n, cz = uniform(sz) / n;
+  double cx = uniform(sx) / n, cy = uniform(sy) / n, cz = uniform(sz) / n;
   const bool ok = n > 0.0 && (cx - cx == 0.0) && (cy - cy == 0.0) && (cz - cz == 0.0);
-  *ox = ok ? cx : 0.0;
-  *oy = ok ? cy : 0.0;
-  *oz = ok ? cz : 0.0;
+  cx = ok ? cx : 0.0;
+  cy = ok ? cy : 0.0;
+  cz = ok ? cz : 0.0;
+  double ext = 0.0;  // the row's extent about that point sets the scale (pow2_scale)
+#pragma unroll
+  for (int k = 0; k < IPT; k++) {
+    const int idx = k * 64 + lane;
+    ext = __builtin_fmax(ext, body_extent(px[idx], px[S + idx], px[2 * S + idx], pm[idx], cx, cy, cz));
+  }
+  for (int o = 32; o > 0; o >>= 1) ext = __builtin_fmax(ext, __shfl_down(ext, o, 64));
+  *ox = cx;
+  *oy = cy;
+  *oz = cz;
+  *scale = uniform(pow2_scale(ext));
 }
 
 template <int IPT, typename T>
@@ -72,24 +83,22 @@ __global__ __launch_bounds__(256) void sym_wave_kernel(const SymArgs a) {
   const int il = blockIdx.x, c = blockIdx.y;  // own row (local index), chunk of its list
   const int I = a.row0 + il;
   const int64_t S = a.S;
-  // double: 2^-300 stands in for "no softening" (nbody_device.hpp); float: plain 0 + a select
-  const T eps2 = static_cast<T>((a.eps2 > 0.0) ? a.eps2 : (kDouble ? kTinyR2 : 0.0));
   T c15 = static_cast<T>(1.5), c1875 = static_cast<T>(1.875);
   asm volatile("" : "+v"(c15), "+v"(c1875));
 
   T xi[IPT], yi[IPT], zi[IPT], mi[IPT], ax[IPT], ay[IPT], az[IPT];
-  double ox = 0.0, oy = 0.0, oz = 0.0;  // float only: see wave_origin
+  double ox = 0.0, oy = 0.0, oz = 0.0, sc = 1.0;  // float only: origin and scale, see wave_origin
   {
     const double *px, *pm;
     block_base<B>(a, I, &px, &pm);
-    if constexpr (!kDouble) wave_origin<IPT>(px, pm, S, lane, &ox, &oy, &oz);
+    if constexpr (!kDouble) wave_origin<IPT>(px, pm, S, lane, &ox, &oy, &oz, &sc);
 #pragma unroll
     for (int k = 0; k < IPT; k++) {
       const int idx = k * 64 + lane;
       if constexpr (!kDouble) {
-        xi[k] = static_cast<T>(px[idx] - ox);
-        yi[k] = static_cast<T>(px[S + idx] - oy);
-        zi[k] = static_cast<T>(px[2 * S + idx] - oz);
+        xi[k] = static_cast<T>((px[idx] - ox) * sc);
+        yi[k] = static_cast<T>((px[S + idx] - oy) * sc);
+        zi[k] = static_cast<T>((px[2 * S + idx] - oz) * sc);
       } else {
         xi[k] = static_cast<T>(px[idx]);
         yi[k] = static_cast<T>(px[S + idx]);
@@ -99,6 +108,9 @@ __global__ __launch_bounds__(256) void sym_wave_kernel(const SymArgs a) {
       ax[k] = ay[k] = az[k] = 0;
     }
   }
+  // double: 2^-300 stands in for "no softening" (nbody_device.hpp); float: plain 0 + a select
+  // (or, softened, eps2 in the row's scaled units)
+  const T eps2 = static_cast<T>((a.eps2 > 0.0) ? a.eps2 * sc * sc : (kDouble ? kTinyR2 : 0.0));
   // do all bodies of this row have one (finite, non-zero) mass?  Every wave holds the whole
   // row: a wave-uniform answer that is the same in all four.
   const T m_ref = __shfl(mi[0], 0, 64);
@@ -108,6 +120,10 @@ __global__ __launch_bounds__(256) void sym_wave_kernel(const SymArgs a) {
   for (int k = 0; k < IPT; k++) row_same = row_same && (mi[k] == m_ref);
   const bool row_uniform = __all(row_same) && !a.no_eq;
   const T inv_m_ref = row_uniform ? inv_probe : 0;
+  // float: units of the row's scale and (uniform row) mass, as in sym_tiles_kernel
+  const double m_unit = (!kDouble && row_uniform) ? static_cast<double>(m_ref) : 1.0;
+  const double stage_m = 1.0 / m_unit;
+  const double unit_i = sc * sc * m_unit;
 
   // this launch's part of the row's list: distances d_lo .. dh, IPT entries each
   int dh = a.d_hi;
@@ -127,8 +143,8 @@ __global__ __launch_bounds__(256) void sym_wave_kernel(const SymArgs a) {
     const int idx = g * 64 + lane;
     P2<T> vxy, vzm;
     if constexpr (!kDouble) {  // relative to the row's origin, narrowed after
-      vxy = P2<T>{static_cast<T>(px[idx] - ox), static_cast<T>(px[S + idx] - oy)};
-      vzm = P2<T>{static_cast<T>(px[2 * S + idx] - oz), static_cast<T>(pm[idx])};
+      vxy = P2<T>{static_cast<T>((px[idx] - ox) * sc), static_cast<T>((px[S + idx] - oy) * sc)};
+      vzm = P2<T>{static_cast<T>((px[2 * S + idx] - oz) * sc), static_cast<T>(pm[idx] * stage_m)};
     } else {
       vxy = P2<T>{static_cast<T>(px[idx]), static_cast<T>(px[S + idx])};
       vzm = P2<T>{static_cast<T>(px[2 * S + idx]), static_cast<T>(pm[idx])};
@@ -140,7 +156,7 @@ __global__ __launch_bounds__(256) void sym_wave_kernel(const SymArgs a) {
       wxy[lane + 64] = vxy;
       wzm[lane + 64] = vzm;
     }
-    const bool equal_mass = __all(vzm.b == m_ref) && row_uniform;
+    const bool equal_mass = __all(static_cast<T>(pm[idx]) == m_ref) && row_uniform;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -167,9 +183,16 @@ __global__ __launch_bounds__(256) void sym_wave_kernel(const SymArgs a) {
       }
       // 64 rotations later the sums are home: lane l holds body l of the group
       double* Cd = a.C + static_cast<int64_t>(d - a.c_base) * 3 * S + static_cast<int64_t>(il) * B;
-      Cd[idx] = fx;
-      Cd[S + idx] = fy;
-      Cd[2 * S + idx] = fz;
+      if constexpr (kDouble) {
+        Cd[idx] = fx;
+        Cd[S + idx] = fy;
+        Cd[2 * S + idx] = fz;
+      } else {  // out of the scaled units (of the common mass too where the group had it)
+        const double unit_j = sc * sc * (equal_mass ? static_cast<double>(m_ref) : 1.0);
+        Cd[idx] = fx * unit_j;
+        Cd[S + idx] = fy * unit_j;
+        Cd[2 * S + idx] = fz * unit_j;
+      }
     } else {  // a group of the row's own block: i side only, every ordered pair
       if (kDouble && row_uniform) NBODY_GROUP(false, kRowUnit);
       else NBODY_GROUP(false, kGeneral);
@@ -204,6 +227,11 @@ __global__ __launch_bounds__(256) void sym_wave_kernel(const SymArgs a) {
         x *= m_ref;
         y *= m_ref;
         z *= m_ref;
+      }
+      if constexpr (!kDouble) {
+        x *= unit_i;
+        y *= unit_i;
+        z *= unit_i;
       }
       Rs[idx] = x;
       Rs[S + idx] = y;
