@@ -130,6 +130,9 @@ enum { kGeneral = 0, kDeferred = 1, kRowUnit = 2, kSameMass = 3 };
 // added when they are home.  Element for element the operations are the scalar path's
 // (IEEE fma / mul / add), in the same order on the i side.
 // SOFT: eps2 >= FLT_MIN, so r^2 > 0 for every pair and nothing has to be done about r^2 == 0.
+#ifndef NBODY_PK_W
+#define NBODY_PK_W 2
+#endif
 typedef float f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ f2 splat(float v) { return f2{v, v}; }
@@ -138,22 +141,24 @@ __device__ __forceinline__ f2 splat(float v) { return f2{v, v}; }
 // give no force:
 //   kZeroNone    nothing -- softened (eps2 >= FLT_MIN), r^2 > 0 for every pair;
 //   kZeroSelect  such a pair's r^2 becomes +inf, whose rsq is 0: 2 instructions a pair;
-//   kZeroTrack   nothing, but the smallest r^2 seen is handed back (one v_min3 per two
-//                pairs): the caller discards the walk's sums and walks again with kZeroSelect
-//                if it was 0.  Off the diagonal tile that takes two bodies in one place.
-enum { kZeroNone = 0, kZeroSelect = 1, kZeroTrack = 2 };
+//   kZeroRedo    nothing in the walk: rsq(0) = inf makes that pair's term inf * 0 = NaN (or
+//                +-inf, where a tiny difference squared to 0) and the body's i-side sum
+//                stays non-finite from there on.  The caller looks at the group's sums
+//                afterwards, discards them and walks again with kZeroSelect if one is not
+//                finite.  Off the diagonal tile that takes two bodies in one place (or
+//                input that is not finite, which then simply comes out again).
+enum { kZeroNone = 0, kZeroSelect = 1, kZeroRedo = 2 };
 
 template <int H, bool SYM, int MODE, int ZERO>
 __device__ __forceinline__ void walk_pk(const P2<float>* xy, const P2<float>* zm, int gb, int lane,
                                         const f2 (&xi2)[H], const f2 (&yi2)[H], const f2 (&zi2)[H],
                                         const f2 (&mi2)[H], f2 (&ax2)[H], f2 (&ay2)[H], f2 (&az2)[H], f2 e2,
-                                        f2* fxo, f2* fyo, f2* fzo, float* least_o) {
+                                        f2* fxo, f2* fyo, f2* fzo) {
   // W packed pairs go through each stage together: neighbours in the instruction stream are
   // then independent (a packed result is not ready for the very next instruction), at W
   // times the live temporaries
-  constexpr int W = H >= 2 ? 2 : 1;
+  constexpr int W = H >= NBODY_PK_W ? NBODY_PK_W : H;
   f2 fx = {0, 0}, fy = {0, 0}, fz = {0, 0};
-  float least = __builtin_inff();
   int rot = lane;
   P2<float> bxy[2], bzm[2];
   bxy[0] = xy[gb + rot];
@@ -189,7 +194,6 @@ __device__ __forceinline__ void walk_pk(const P2<float>* xy, const P2<float>* zm
             r2[k].x = (r2[k].x > 0.0f) ? r2[k].x : __builtin_inff();
             r2[k].y = (r2[k].y > 0.0f) ? r2[k].y : __builtin_inff();
           }
-          if (ZERO == kZeroTrack) least = __builtin_fminf(__builtin_fminf(least, r2[k].x), r2[k].y);
           y0[k] = f2{__builtin_amdgcn_rsqf(r2[k].x), __builtin_amdgcn_rsqf(r2[k].y)};
         }
 #pragma unroll
@@ -228,7 +232,6 @@ __device__ __forceinline__ void walk_pk(const P2<float>* xy, const P2<float>* zm
   *fxo = fx;
   *fyo = fy;
   *fzo = fz;
-  *least_o = least;
 }
 
 template <int IPT, bool SYM, int MODE, bool SOFT>
@@ -251,16 +254,18 @@ __device__ __forceinline__ void group_steps_pk(const P2<float>* xy, const P2<flo
   }
   const f2 e2 = splat(eps2);
   f2 fx, fy, fz;
-  float least;
   // the diagonal tile meets every body with itself: selects from the start
-  constexpr int kFirst = SOFT ? kZeroNone : (SYM ? kZeroTrack : kZeroSelect);
-  walk_pk<H, SYM, MODE, kFirst>(xy, zm, gb, lane, xi2, yi2, zi2, mi2, gx, gy, gz, e2, &fx, &fy, &fz, &least);
-  if constexpr (kFirst == kZeroTrack) {
-    if (__builtin_expect(__any(!(least > 0.0f)), 0)) {  // (also: a NaN in the walk's r^2 ... stays one)
+  constexpr int kFirst = SOFT ? kZeroNone : (SYM ? kZeroRedo : kZeroSelect);
+  walk_pk<H, SYM, MODE, kFirst>(xy, zm, gb, lane, xi2, yi2, zi2, mi2, gx, gy, gz, e2, &fx, &fy, &fz);
+  if constexpr (kFirst == kZeroRedo) {
+    f2 all = gx[0] + gy[0] + gz[0];  // finite iff every term is (inf - inf = NaN)
+#pragma unroll
+    for (int k = 1; k < H; k++) all += gx[k] + gy[k] + gz[k];
+    const float probe = all.x + all.y;
+    if (__builtin_expect(__any(!(probe - probe == 0.0f)), 0)) {
 #pragma unroll
       for (int k = 0; k < H; k++) gx[k] = gy[k] = gz[k] = f2{0, 0};
-      walk_pk<H, SYM, MODE, kZeroSelect>(xy, zm, gb, lane, xi2, yi2, zi2, mi2, gx, gy, gz, e2, &fx, &fy, &fz,
-                                         &least);
+      walk_pk<H, SYM, MODE, kZeroSelect>(xy, zm, gb, lane, xi2, yi2, zi2, mi2, gx, gy, gz, e2, &fx, &fy, &fz);
     }
   }
 #pragma unroll
