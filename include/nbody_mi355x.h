@@ -51,7 +51,10 @@ typedef enum {
                                sums; in the pair-symmetric kernels also the separations, taken
                                from coordinates RELATIVE to the row's centroid (subtracted in
                                double, then narrowed), so that a system far from the origin
-                               loses nothing; state, integration and snapshots stay double.
+                               loses nothing, and SCALED by a power of two per row, so that
+                               neither r^2 nor r^-3 leaves float's range in a scene of any size
+                               (masses must be float-representable: 1e-38 .. 3e38); state,
+                               integration and snapshots stay double.
                                Systems of at most NBODY_MI355X_WAVE_MAX_BODIES bodies are
                                latency-bound and run the double kernels either way (faster there) */
 
