@@ -242,6 +242,8 @@ def main():
                     help="plummer: BASELINE configs 3/4 (seed 42, dt 1e-3); cube: config 5 (uniform cube, seed 7, dt 1e-4)")
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--precision", choices=["fp64", "fp32"], default="fp64")
+    ap.add_argument("--integrator", choices=["euler", "kick_drift", "kdk"], default="euler",
+                    help="euler = the reference's (the headline); kdk = leapfrog, one more O(N) kernel per step")
     ap.add_argument("--no-overlap", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true",
@@ -295,7 +297,8 @@ def main():
         (p, m), dt, scene = nb.ic_uniform_cube(n, 7), 1e-4, f"uniform_cube_n{n}_{args.precision}_seed7_dt1e-4"
     sim = ShardedNBody(p, m, dt, rank=rank, world=world, device=device,
                        backend=HipBackend(precision=prec, variant=args.variant),
-                       overlap=not args.no_overlap, force_collectives=args.force_collectives)
+                       overlap=not args.no_overlap, force_collectives=args.force_collectives,
+                       integrator={"euler": nb.EULER, "kick_drift": nb.KICK_DRIFT, "kdk": nb.KDK}[args.integrator])
     del p, m
 
     def barrier():
@@ -364,7 +367,7 @@ def main():
                                        + " per step"
                                        + ("" if args.no_overlap or world == 1 else ", all-gather overlapped with the own-slab part")),
                        "kernel": kernel_label,
-                       "kernel_variant": args.variant},
+                       "kernel_variant": args.variant, "integrator": args.integrator},
             "roofline": {"bound": "valu_fp64" if prec == nb.FP64 else "valu_fp32", "achieved": round(ach, 3),
                          "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                          # PMC bytes (profiles/traffic.json holds them per STEP), per launch like `achieved`

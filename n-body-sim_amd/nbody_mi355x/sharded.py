@@ -21,6 +21,12 @@ its own stream), the rank already accumulates the forces from its OWN slab,
 which it holds (step_args.acc_out, first half of a split step); after
 work.wait() a second launch adds the remote slabs and integrates.
 
+Integrators: the reference's forward Euler (default), the symplectic Euler step, and the
+kick-drift-kick leapfrog of include/nbody_mi355x.h (KDK): a small step is then a drift of
+the own slab (v += dt/2 a, r += dt v), the exchange, and the force evaluation at the new
+positions whose epilogue is the second kick -- still one force evaluation and the same two
+collectives per small step.
+
 torch is plumbing here (device memory, streams, torch.distributed); the
 arithmetic is in libnbody_mi355x.so.  `backend` exists so that the CPU test of
 this host logic (gloo, world_size 2) can substitute a checker for the kernel;
@@ -33,7 +39,8 @@ import ctypes as C
 import numpy as np
 import torch
 
-from . import FP64, G_REFERENCE, SYM_VARIANTS, TILE, VARIANT_SYM, VARIANT_SYM8, VARIANT_SYMW8, StepArgs, check, lib, round_up
+from . import (EULER, FP64, G_REFERENCE, KDK, KICK_DRIFT, SYM_VARIANTS, TILE, VARIANT_SYM, VARIANT_SYM8, VARIANT_SYMW8,
+               StepArgs, check, lib, round_up)
 
 SYM_MIN_BODIES = 2048  # as kSymMinBodies in csrc/nbody_kernels.hip
 
@@ -61,6 +68,14 @@ class HipBackend:
         check(self._lib.nbody_mi355x_step_workspace_bytes(C.byref(a), C.byref(need)))
         return need.value
 
+    def workspace_min_bytes(self, S, world):
+        """The smallest workspace they accept (the distances are then walked in more batches)."""
+        a = StepArgs()
+        a.shard_slots, a.num_shards, a.variant, a.precision = S, world, self.variant, self.precision
+        least = C.c_int64(0)
+        check(self._lib.nbody_mi355x_step_workspace_min_bytes(C.byref(a), C.byref(least)))
+        return least.value
+
     def tile_launches(self, S, world, count, n, workspace, variant=None):
         """Launches of the force kernel per whole step for this layout and workspace (distance batches)."""
         a = StepArgs()
@@ -76,7 +91,7 @@ class HipBackend:
         return out.value
 
     def step(self, *, pos_cur, pos_next, mass, vel, acc_in, acc_out, snapshot, S, world, rank, count,
-             ranges, dt, G, eps2, workspace=None, phase=0, variant=None):
+             ranges, dt, G, eps2, workspace=None, phase=0, variant=None, integrator=EULER, kdk_acc=None):
         a = StepArgs()
         a.pos_cur, a.pos_next, a.mass, a.vel = pos_cur.data_ptr(), pos_next.data_ptr(), mass.data_ptr(), vel.data_ptr()
         a.acc_in = acc_in.data_ptr() if acc_in is not None else None
@@ -87,20 +102,35 @@ class HipBackend:
         a.dt, a.G, a.eps2 = dt, G, eps2
         a.precision, a.variant = self.precision, self.variant if variant is None else variant
         a.phase = phase
+        a.integrator = integrator
+        a.kdk_acc = kdk_acc.data_ptr() if kdk_acc is not None else None
         if workspace is not None:
             a.workspace, a.workspace_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
         stream = torch.cuda.current_stream(pos_cur.device).cuda_stream
         check(self._lib.nbody_mi355x_step_f64(C.byref(a), C.c_void_p(stream)))
 
+    def kdk_drift(self, *, pos_cur, pos_next, vel, kdk_acc, S, world, rank, count, dt, G):
+        """First half of a leapfrog small step for the own slab (nbody_mi355x_kdk_drift_f64)."""
+        a = StepArgs()
+        a.pos_cur, a.pos_next, a.vel, a.kdk_acc = pos_cur.data_ptr(), pos_next.data_ptr(), vel.data_ptr(), kdk_acc.data_ptr()
+        a.shard_slots, a.num_shards, a.own_shard, a.own_count = S, world, rank, count
+        a.dt, a.G = dt, G
+        stream = torch.cuda.current_stream(pos_cur.device).cuda_stream
+        check(self._lib.nbody_mi355x_kdk_drift_f64(C.byref(a), C.c_void_p(stream)))
+
 
 class ShardedNBody:
     def __init__(self, particles, mass, dt, *, rank=0, world=1, device="cuda", G=G_REFERENCE, eps2=0.0,
-                 backend=None, overlap=True, group=None, use_workspace=True, force_collectives=False):
+                 backend=None, overlap=True, group=None, use_workspace=True, force_collectives=False,
+                 integrator=EULER):
         particles = np.ascontiguousarray(particles, dtype=np.float64).reshape(-1, 6)
         mass = np.ascontiguousarray(mass, dtype=np.float64)
         self.n, self.rank, self.world = particles.shape[0], rank, world
         self.dt, self.G, self.eps2 = float(dt), float(G), float(eps2)
         self.overlap, self.group = overlap, group
+        if integrator not in (EULER, KICK_DRIFT, KDK):
+            raise ValueError(f"integrator {integrator}: EULER, KICK_DRIFT or KDK")
+        self.integrator = integrator
         # rehearsal: take the multi-rank code path (collectives, split steps, partial-sum
         # exchange) even with one rank, so that RCCL itself can be exercised on a one-GPU box
         self.multi = world > 1 or force_collectives
@@ -140,24 +170,52 @@ class ShardedNBody:
         self.acc_all = None
         if (use_workspace and hasattr(self.backend, "workspace_bytes") and self.device.type == "cuda"
                 and (variant in SYM_VARIANTS or (variant == 0 and self.n >= SYM_MIN_BODIES))):
+            # the preferred size if it is under half of the free memory, else what is under
+            # half of it down to the kernels' minimum (as nbody_mi355x_create does)
             need = self.backend.workspace_bytes(S, world)
             free_b, _ = torch.cuda.mem_get_info(self.device)
-            if 0 < need < free_b // 2:
+            budget = free_b // 2 - (3 * S * world * 8 if self.multi else 0)
+            if need > budget and need > 0:
+                least = self.backend.workspace_min_bytes(S, world)
+                need = budget if 0 < least <= budget else 0
+            if need > 0:
                 self.workspace = torch.empty(need // 8, dtype=torch.float64, device=dev)
                 if self.multi:
                     self.acc_all = torch.zeros((world, 3, S), dtype=torch.float64, device=dev)
         self.sym_variant = variant if variant in SYM_VARIANTS else VARIANT_SYM
+        # leapfrog: the raw sums of the last force evaluation, own slab (the next drift's kick)
+        self.kacc = torch.zeros((3, S), dtype=torch.float64, device=dev) if integrator == KDK else None
+        self._kdk_primed = False
         self._send = self._recv = None
         self.cur = 0
         self._fresh = True  # every slab of pos[cur] is current (true right after upload)
 
     # ------------------------------------------------------------------ one small step
     def step(self, snapshot=False):
+        snap = self.snap if snapshot else None
+        if self.integrator != KDK:
+            self._evaluate(snap, self.dt)       # forces at pos[cur]; the update writes pos[cur ^ 1]
+            self.cur ^= 1
+            self._fresh = False
+            return
+        if not self._kdk_primed:                # a(r0): a KDK evaluation with dt = 0 moves nothing
+            self._evaluate(None, 0.0)
+            self._kdk_primed = True
+        cur, nxt = self.pos[self.cur], self.pos[self.cur ^ 1]
+        self.backend.kdk_drift(pos_cur=cur, pos_next=nxt, vel=self.vel, kdk_acc=self.kacc, S=self.S, world=self.world,
+                               rank=self.rank, count=self.count, dt=self.dt, G=self.G)
+        self.cur ^= 1
+        self._fresh = False
+        self._evaluate(snap, self.dt)           # forces at the new positions + the second kick; nothing moves
+
+    def _evaluate(self, snap, dt):
+        """One force evaluation at pos[cur] and the integrator's epilogue (exchange included)."""
         cur, nxt = self.pos[self.cur], self.pos[self.cur ^ 1]
         S, P, r = self.S, self.world, self.rank
         common = dict(pos_cur=cur, pos_next=nxt, mass=self.mass, vel=self.vel, S=S, world=P, rank=r,
-                      count=self.count, dt=self.dt, G=self.G, eps2=self.eps2)
-        snap = self.snap if snapshot else None
+                      count=self.count, dt=dt, G=self.G, eps2=self.eps2)
+        if self.integrator != EULER:            # (a backend without integrators keeps its signature)
+            common.update(integrator=self.integrator, kdk_acc=self.kacc)
         if not self.multi:
             extra = {"workspace": self.workspace} if self.workspace is not None else {}
             self.backend.step(acc_in=None, acc_out=None, snapshot=snap, ranges=((0, self.n), (0, 0)), **common, **extra)
@@ -176,8 +234,6 @@ class ShardedNBody:
             work.wait()                                           # stream-ordered, not a host block
             self.backend.step(acc_in=self.acc, acc_out=None, snapshot=snap,
                               ranges=((0, r * S), ((r + 1) * S, P * S)), **common)
-        self.cur ^= 1
-        self._fresh = False
 
     # -- pair-symmetric step over several ranks, in its three parts (the one-GPU loop-back
     # test drives them separately): partial sums for EVERY slot -> reduce-scatter -> integrate
@@ -204,7 +260,7 @@ class ShardedNBody:
             self.acc.copy_(host[self.rank])
 
     def _integrate(self, common, snap):
-        # a one-sided step with no j range: acc_in -> Euler update (+ snapshot)
+        # a one-sided step with no j range: acc_in -> the integrator's update (+ snapshot)
         self.backend.step(acc_in=self.acc, acc_out=None, snapshot=snap, ranges=((0, 0), (0, 0)), variant=1, **common)
 
     def _all_gather(self, buf, async_op):

@@ -177,7 +177,7 @@ def test_symmetric_phases_equal_whole(variant):
     assert whole.abs().max() > 0
 
 
-def _rank_main(rank, world, port, n, steps, q):
+def _rank_main(rank, world, port, n, steps, q, integrator=0):
     """A real rank of the sharded driver (own process, own process group); the two ranks
     share the one GPU of the test box and talk over gloo, staged through the host."""
     import os
@@ -195,7 +195,7 @@ def _rank_main(rank, world, port, n, steps, q):
         import nbody_mi355x as nb
         from nbody_mi355x.sharded import ShardedNBody
         p, m = nb.ic_plummer(n, 31)
-        sim = ShardedNBody(p, m, 1e-3, rank=rank, world=world, device="cuda:0", overlap=True)
+        sim = ShardedNBody(p, m, 1e-3, rank=rank, world=world, device="cuda:0", overlap=True, integrator=integrator)
         for k in range(steps):
             sim.step(snapshot=(k == steps - 1))
         torch.cuda.synchronize()
@@ -233,6 +233,48 @@ def test_two_real_ranks_end_to_end(n, expect_sym, world):
     assert rel_pos_err(snap[:, :3], out[0, :, :3]) <= 1e-13
     num = np.linalg.norm(snap[:, 6:9] - out[0, :, 6:9], axis=1)
     assert (num / np.linalg.norm(out[0, :, 6:9], axis=1)).max() <= 1e-12
+
+
+@pytest.mark.parametrize("integrator", ["KICK_DRIFT", "KDK"])
+@pytest.mark.parametrize("n,expect_sym,world", [(1500, False, 2), (20000, True, 2), (20000, True, 3)])
+def test_real_ranks_other_integrators(n, expect_sym, world, integrator):
+    """The sharded driver with the symplectic Euler step and the kick-drift-kick leapfrog (a
+    drift of the own slab, the exchange, one force evaluation whose epilogue is the second
+    kick): real ranks sharing the box's GPU, one-sided split steps and pair-symmetric partial
+    sums, against the C handle's own sequencing of the same integrator on one device (which
+    fuses {kick, kick, drift} between small steps: the same operations in another grouping)."""
+    import socket
+    import torch.multiprocessing as mp
+    which = getattr(nb, integrator)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    steps = 6
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rank_main, args=(r, world, port, n, steps, q, which)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    res = sorted((q.get(timeout=100) for _ in range(world)), key=lambda t: t[0])
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    assert all(r[3] == expect_sym for r in res)
+    p, m = nb.ic_plummer(n, 31)
+    with nb.Simulation(n, 1e-3, integrator=which) as sim:
+        sim.upload(p, m)
+        out = sim.run(steps, snapshot=True)
+        fin = sim.download()
+    state = np.concatenate([r[1] for r in res])
+    snap = np.concatenate([r[2] for r in res])
+    assert rel_pos_err(state[:, :3], fin[:, :3]) <= 1e-13
+    assert rel_pos_err(snap[:, :3], out[:, :3]) <= 1e-13
+    assert np.abs(snap[:, 3:6] - out[:, 3:6]).max() <= 1e-12 * np.abs(out[:, 3:6]).max()
+    num = np.linalg.norm(snap[:, 6:9] - out[:, 6:9], axis=1)
+    assert (num / np.linalg.norm(out[:, 6:9], axis=1)).max() <= 1e-11
+    # ... and it is not the Euler step: the integrators differ at O(dt^2) per step
+    euler, _ = ol.simulate(p, m, 1, steps, 1e-3, threads=16)
+    assert rel_pos_err(state[:, :3], euler[:, :3]) > 1e-9
 
 
 def _rccl_single_rank_main(port, n, steps, q):
