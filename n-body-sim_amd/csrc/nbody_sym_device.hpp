@@ -120,7 +120,7 @@ constexpr int kGrp = 72;
 enum { kGeneral = 0, kDeferred = 1, kRowUnit = 2, kSameMass = 3 };
 
 // The FP32 walk with PACKED arithmetic: two of the lane's bodies per instruction.
-// Measured on gfx950 (tools/ubench/valu_rates.hip, ns per wave instruction per SIMD):
+// Measured on gfx950 (tools/ubench_valu_rates.hip, ns per wave instruction per SIMD):
 // v_fma_f32 1.6, v_pk_fma_f32 2.0 for two FMAs; v_mul/v_sub_f32 1.1, v_pk_mul/v_pk_add_f32
 // 1.9 for two -- the 9 FMAs of a pair are what packing pays for.  The j body arrives from LDS
 // as two 64-bit pairs {x,y} {z,m}, and a packed instruction can take either half of a pair

@@ -1,7 +1,7 @@
-// valu_rates.hip -- issue rates of the VALU instructions the FP32 step is made of, measured:
+// ubench_valu_rates.hip -- issue rates of the VALU instructions the FP32 step is made of, measured:
 // cycles per wave64 instruction of v_fma_f32, v_pk_fma_f32, v_rsq_f32, v_fma_f64, v_rsq_f64,
 // a DPP row rotation, and mixes of them.  Every SIMD gets 2 waves of independent chains.
-// Build: hipcc --offload-arch=gfx950 -O3 -o valu_rates valu_rates.hip ; run: ./valu_rates
+// Build: make -C tools ubench_valu_rates ; run: tools/ubench_valu_rates
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
