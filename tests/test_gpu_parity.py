@@ -817,6 +817,27 @@ def test_handle_shrinks_its_workspace_before_giving_up_the_symmetric_kernels(mon
         one = sim.run(2, snapshot=True)
     assert variant not in nb.SYM_VARIANTS and held == 0
     assert rel_pos_err(one[:, :3], ref[0, :, :3]) <= 1e-14
+    # a multi-shard handle does the same per device (its exchange buffers come out of the budget first)
+    a.shard_slots, a.num_shards = 20480, 2
+    nb.check(nb.lib().nbody_mi355x_step_workspace_bytes(C.byref(a), C.byref(pref)))
+    nb.check(nb.lib().nbody_mi355x_step_workspace_min_bytes(C.byref(a), C.byref(least)))
+    exchange = 2 * (2 * 3 * 20480 * 8)                    # acc_all + staging, per device
+    budget = ((least.value + exchange) >> 20) + 2
+    assert (budget << 20) - exchange < pref.value
+    monkeypatch.setenv("NBODY_MI355X_WS_BUDGET_MB", str(budget))
+    with nb.Simulation(n, 1e-3, devices=[0, 0]) as sim:
+        variant, held = sim.kernel_in_use()
+        sim.upload(p, m)
+        two = sim.run(2, snapshot=True)
+    assert variant in nb.SYM_VARIANTS and least.value <= held <= budget << 20
+    assert rel_pos_err(two[:, :3], ref[0, :, :3]) <= 1e-14
+    monkeypatch.setenv("NBODY_MI355X_WS_BUDGET_MB", "1")
+    with nb.Simulation(n, 1e-3, devices=[0, 0]) as sim:
+        variant, held = sim.kernel_in_use()
+        sim.upload(p, m)
+        two = sim.run(2, snapshot=True)
+    assert variant not in nb.SYM_VARIANTS and held == 0
+    assert rel_pos_err(two[:, :3], ref[0, :, :3]) <= 1e-14
 
 
 @pytest.mark.parametrize("n,kw", [(300, {}), (5000, {})])
