@@ -141,8 +141,8 @@ __global__ __launch_bounds__(256) void sym_tiles_kernel(const SymArgs a) {
       ax[k] = ay[k] = az[k] = 0;
     }
   }
-  // double: 2^-300 stands in for "no softening" (nbody_device.hpp); float: plain 0 + a select
-  // (or, softened, eps2 in the row's scaled units)
+  // double: 2^-300 stands in for "no softening" (nbody_device.hpp); float: plain 0 (r^2 == 0
+  // is dealt with in the walk, nbody_sym_device.hpp) or, softened, eps2 in the row's scaled units
   const T eps2 = static_cast<T>((a.eps2 > 0.0) ? a.eps2 * sc * sc : (sizeof(T) == sizeof(double) ? kTinyR2 : 0.0));
   // do all bodies of this row have one (finite, non-zero) mass?  Workgroup-uniform answer.
   __shared__ T m_row;

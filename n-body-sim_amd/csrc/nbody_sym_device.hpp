@@ -64,9 +64,9 @@ __device__ __forceinline__ float fma_t(float a, float b, float c) { return __bui
 // The two weights of one pair from its separation: si = m_j r^-3 (applied to body i) and
 // sj = m_i r^-3 (applied to body j; only computed when WANT_J).
 // double: rsq seed + folded series, r^2 chain seeded with 2^-300 or eps2 (nbody_device.hpp).
-// float (the FP32 variant): v_rsq_f32 is good to an ulp; r^2 == 0 is an explicit select
-// because 2^-300 does not exist in float; and the mass is multiplied in BEFORE the cube is
-// completed, (m y0) (y0 y0), so that r^-3 alone never underflows (r = 1e13 m: 1e-39).
+// float (the FP32 variant), one body per lane only (two and more take the packed walk below):
+// v_rsq_f32 is good to an ulp; r^2 == 0 is an explicit select because 2^-300 does not exist in
+// float; the mass is multiplied in BEFORE the cube is completed, (m y0) (y0 y0).
 __device__ __forceinline__ double pair_r3(double dx, double dy, double dz, double eps2, double c15, double c1875) {
   const double r2 = __builtin_fma(dz, dz, __builtin_fma(dy, dy, __builtin_fma(dx, dx, eps2)));
   const double y0 = __builtin_amdgcn_rsq(r2);

@@ -108,8 +108,8 @@ __global__ __launch_bounds__(256) void sym_wave_kernel(const SymArgs a) {
       ax[k] = ay[k] = az[k] = 0;
     }
   }
-  // double: 2^-300 stands in for "no softening" (nbody_device.hpp); float: plain 0 + a select
-  // (or, softened, eps2 in the row's scaled units)
+  // double: 2^-300 stands in for "no softening" (nbody_device.hpp); float: plain 0 (r^2 == 0
+  // is dealt with in the walk, nbody_sym_device.hpp) or, softened, eps2 in the row's scaled units
   const T eps2 = static_cast<T>((a.eps2 > 0.0) ? a.eps2 * sc * sc : (kDouble ? kTinyR2 : 0.0));
   // do all bodies of this row have one (finite, non-zero) mass?  Every wave holds the whole
   // row: a wave-uniform answer that is the same in all four.
