@@ -244,6 +244,8 @@ def main():
     ap.add_argument("--precision", choices=["fp64", "fp32"], default="fp64")
     ap.add_argument("--integrator", choices=["euler", "kick_drift", "kdk"], default="euler",
                     help="euler = the reference's (the headline); kdk = leapfrog, one more O(N) kernel per step")
+    ap.add_argument("--device-ics", action="store_true",
+                    help="make the scene on the device(s), one random stream per body (statistically the default scene, not bit for bit)")
     ap.add_argument("--no-overlap", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true",
@@ -291,7 +293,12 @@ def main():
 
     n, K, W = args.n, args.steps, args.warmup
     prec = nb.FP64 if args.precision == "fp64" else nb.FP32
-    if args.ic == "plummer":                          # same ICs on every rank
+    if args.device_ics:                               # every rank makes the bodies it holds, on its GPU
+        kind, seed, dt = (nb.SCENE_PLUMMER, 42, 1e-3) if args.ic == "plummer" else (nb.SCENE_UNIFORM_CUBE, 7, 1e-4)
+        p, m = nb.make_scene(kind, n, seed=seed), None
+        scene = (f"{'plummer_sphere' if args.ic == 'plummer' else 'uniform_cube'}_n{n}_{args.precision}_seed{seed}_dt{dt:g}"
+                 "_one_stream_per_body_made_on_device")
+    elif args.ic == "plummer":                        # same ICs on every rank
         (p, m), dt, scene = nb.ic_plummer(n, 42), 1e-3, f"plummer_sphere_n{n}_{args.precision}_seed42_dt1e-3"
     else:
         (p, m), dt, scene = nb.ic_uniform_cube(n, 7), 1e-4, f"uniform_cube_n{n}_{args.precision}_seed7_dt1e-4"

@@ -338,6 +338,47 @@ int nbody_mi355x_ic_ring(int64_t n, uint64_t seed, double central_mass, double r
                          double width_sigma, double thickness_sigma, double v_sigma,
                          double mass_sigma, double* particles, double* mass);
 
+/* ------------------------------- initial conditions at scale (device, and host threads)
+ * The same scenes with ONE STREAM PER BODY (seeded from (seed, body index)), so that body i
+ * is a pure function of (scene, i): any range of bodies can be made anywhere -- a GPU thread
+ * per body, straight into the slab layout, or a host thread per range -- SURVEY 8f-3.  The
+ * reference draws a whole scene from one libstdc++ stream on the host, a SetParticle() at a
+ * time (saturn_ring.cc:42-63, particle_initializer.h:120-175); nbody_mi355x_ic_* above keep
+ * that shape.  A scene made here is statistically, not bit for bit, the scene ic_* makes from
+ * the same seed; device and host agree with each other up to the last bits of pow/log/cos. */
+#define NBODY_MI355X_SCENE_PLUMMER 0      /* as ic_plummer; the centre of mass and the mean
+                                             velocity are removed by nbody_mi355x_generate only */
+#define NBODY_MI355X_SCENE_UNIFORM_CUBE 1 /* as ic_uniform_cube */
+#define NBODY_MI355X_SCENE_RING 2         /* as ic_ring (body 0: the central mass)            */
+typedef struct nbody_mi355x_scene {
+  int32_t scene;         /* NBODY_MI355X_SCENE_*                                */
+  int32_t reserved;      /* 0                                                   */
+  uint64_t seed;
+  int64_t num_particles; /* bodies of the WHOLE scene (masses are 1 / (G n))    */
+  double G;              /* PLUMMER / UNIFORM_CUBE: units G * M_total = 1       */
+  double central_mass, ring_radius, width_sigma, thickness_sigma, v_sigma, mass_sigma; /* RING */
+} nbody_mi355x_scene;
+/* Level 1: bodies [first, first + count) of the scene into one slab of the device layout
+ * (pos_slab: x at +0, y at +shard_slots, z at +2*shard_slots; vel likewise, or NULL for a
+ * slab whose velocities live elsewhere; mass_slab[count]).  Asynchronous on `stream`. */
+int nbody_mi355x_scene_fill_f64(const nbody_mi355x_scene* scene, int64_t first, int64_t count,
+                                double* pos_slab, double* vel, double* mass_slab, int64_t shard_slots,
+                                void* stream);
+/* sums6 (device, 6 doubles) = sums of the slab's first `count` positions and (vel != NULL)
+ * velocities, added in a fixed order; and pos -= shift6[0..2], vel -= shift6[3..5] (host
+ * values).  What removing a centre of mass takes. */
+int nbody_mi355x_slab_sums_f64(const double* pos_slab, const double* vel, int64_t count,
+                               int64_t shard_slots, double* sums6, void* stream);
+int nbody_mi355x_slab_shift_f64(double* pos_slab, double* vel, int64_t count, int64_t shard_slots,
+                                const double* shift6, void* stream);
+/* The same bodies on the host, on up to 16 threads: Particle<double>[count], double[count]. */
+int nbody_mi355x_scene_host(const nbody_mi355x_scene* scene, int64_t first, int64_t count,
+                            double* particles, double* mass);
+/* Level 2: the whole scene straight into the handle's device state, in place of upload()
+ * (scene->num_particles must be the handle's); on a multi-device handle every device makes
+ * the bodies it holds.  PLUMMER: centre of mass and mean velocity are removed. */
+int nbody_mi355x_generate(nbody_mi355x_sim* sim, const nbody_mi355x_scene* scene);
+
 #ifdef __cplusplus
 }
 #endif

@@ -57,6 +57,8 @@ struct MultiSim;
 int multi_create(const nbody_mi355x_config& cfg, const int32_t* devices, int32_t num, MultiSim** out);
 int multi_destroy(MultiSim* m);
 int multi_upload(MultiSim* m, const double* particles, const double* mass);
+int multi_generate(MultiSim* m, const nbody_mi355x_scene& scene);
+bool scene_valid(const nbody_mi355x_scene* scene, const char* who);  // nbody_scene.hip; sets the error text
 int multi_enqueue(MultiSim* m, int64_t substeps, double* snapshot_out);
 int multi_wait(MultiSim* m, double* seconds);
 int multi_download(MultiSim* m, double* particles);

@@ -549,6 +549,68 @@ int multi_upload(MultiSim* m, const double* particles, const double* mass) {
   return NBODY_MI355X_OK;
 }
 
+// The scene made where it is held: every device fills all P slabs of its position and mass
+// buffers (O(N) per device, no exchange) and its own slab's velocities.
+int multi_generate(MultiSim* m, const nbody_mi355x_scene& sc) {
+  const int P = m->P;
+  const int64_t S = m->S;
+  const size_t all = sizeof(double) * 3 * static_cast<size_t>(S) * P;
+  for (int o = 0; o < P; o++) {
+    Shard& s = m->sh[o];
+    M_TRY(hipSetDevice(s.device), NBODY_MI355X_ERR_NO_DEVICE, "hipSetDevice");
+    // padding slots: mass 0 at the origin
+    M_TRY(hipMemsetAsync(s.pos[0], 0, all, s.stream), NBODY_MI355X_ERR_H2D, "memset positions");
+    M_TRY(hipMemsetAsync(s.mass, 0, sizeof(double) * static_cast<size_t>(S) * P, s.stream), NBODY_MI355X_ERR_H2D,
+          "memset masses");
+    M_TRY(hipMemsetAsync(s.vel, 0, sizeof(double) * 3 * static_cast<size_t>(S), s.stream), NBODY_MI355X_ERR_H2D,
+          "memset velocities");
+    for (int r = 0; r < P; r++) {
+      const int rc = nbody_mi355x_scene_fill_f64(&sc, m->sh[r].begin, m->sh[r].count, s.pos[0] + static_cast<size_t>(r) * 3 * S,
+                                                 r == o ? s.vel : nullptr, s.mass + static_cast<size_t>(r) * S, S, s.stream);
+      if (rc != NBODY_MI355X_OK) return rc;
+    }
+  }
+  if (sc.scene == NBODY_MI355X_SCENE_PLUMMER) {
+    // centre-of-mass frame: every device sums its own slab (positions and velocities), the host
+    // adds the P partial sums in shard order, every device shifts what it holds
+    std::vector<double> part(static_cast<size_t>(P) * 6);
+    for (int o = 0; o < P; o++) {
+      Shard& s = m->sh[o];
+      M_TRY(hipSetDevice(s.device), NBODY_MI355X_ERR_NO_DEVICE, "hipSetDevice");
+      const int rc = nbody_mi355x_slab_sums_f64(s.pos[0] + static_cast<size_t>(o) * 3 * S, s.vel, s.count, S, s.acc, s.stream);
+      if (rc != NBODY_MI355X_OK) return rc;
+      M_TRY(hipMemcpyAsync(&part[static_cast<size_t>(o) * 6], s.acc, 6 * sizeof(double), hipMemcpyDeviceToHost, s.stream),
+            NBODY_MI355X_ERR_D2H, "copy sums");
+    }
+    double shift[6] = {0, 0, 0, 0, 0, 0};
+    for (int o = 0; o < P; o++) {
+      M_TRY(hipSetDevice(m->sh[o].device), NBODY_MI355X_ERR_NO_DEVICE, "hipSetDevice");
+      M_TRY(hipStreamSynchronize(m->sh[o].stream), NBODY_MI355X_ERR_D2H, "generate sync");
+      for (int c = 0; c < 6; c++) shift[c] += part[static_cast<size_t>(o) * 6 + c];
+    }
+    for (double& v : shift) v /= static_cast<double>(m->n);
+    for (int o = 0; o < P; o++) {
+      Shard& s = m->sh[o];
+      M_TRY(hipSetDevice(s.device), NBODY_MI355X_ERR_NO_DEVICE, "hipSetDevice");
+      for (int r = 0; r < P; r++) {
+        const int rc = nbody_mi355x_slab_shift_f64(s.pos[0] + static_cast<size_t>(r) * 3 * S, r == o ? s.vel : nullptr,
+                                                   m->sh[r].count, S, shift, s.stream);
+        if (rc != NBODY_MI355X_OK) return rc;
+      }
+    }
+  }
+  for (int o = 0; o < P; o++) {
+    Shard& s = m->sh[o];
+    M_TRY(hipSetDevice(s.device), NBODY_MI355X_ERR_NO_DEVICE, "hipSetDevice");
+    M_TRY(hipMemcpyAsync(s.pos[1], s.pos[0], all, hipMemcpyDeviceToDevice, s.stream), NBODY_MI355X_ERR_H2D,
+          "copy positions");
+    M_TRY(hipStreamSynchronize(s.stream), NBODY_MI355X_ERR_LAUNCH, "generate sync");
+  }
+  m->cur = 0;
+  m->kacc_valid = false;
+  return NBODY_MI355X_OK;
+}
+
 // Enqueues a big step on every shard's stream and returns; multi_wait completes it.
 int multi_enqueue(MultiSim* m, int64_t substeps, double* snapshot_out) {
   for (Shard& s : m->sh) {

@@ -247,6 +247,42 @@ extern "C" int nbody_mi355x_upload(nbody_mi355x_sim* s, const void* particles, c
   return NBODY_MI355X_OK;
 }
 
+extern "C" int nbody_mi355x_generate(nbody_mi355x_sim* s, const nbody_mi355x_scene* sc) {
+  if (!s || !sc) { set_error("generate: null argument"); return NBODY_MI355X_ERR_INVALID; }
+  if (!nbody_internal::scene_valid(sc, "generate")) return NBODY_MI355X_ERR_INVALID;  // before anything is touched
+  if (sc->num_particles != s->n) {
+    set_error("generate: a scene of %lld bodies for a handle of %lld", (long long)sc->num_particles, (long long)s->n);
+    return NBODY_MI355X_ERR_INVALID;
+  }
+  if (s->pending) { const int wrc = nbody_mi355x_wait(s); if (wrc != NBODY_MI355X_OK) return wrc; }
+  if (s->multi) return nbody_internal::multi_generate(s->multi, *sc);
+  HIP_TRY(hipSetDevice(s->cfg.device), NBODY_MI355X_ERR_NO_DEVICE, "hipSetDevice");
+  const size_t slab = sizeof(double) * 3 * static_cast<size_t>(s->slots);
+  // padding slots: mass 0 at the origin, in both position buffers, never written again
+  HIP_TRY(hipMemsetAsync(s->pos[0], 0, slab, s->stream), NBODY_MI355X_ERR_H2D, "memset pos0");
+  HIP_TRY(hipMemsetAsync(s->pos[1], 0, slab, s->stream), NBODY_MI355X_ERR_H2D, "memset pos1");
+  HIP_TRY(hipMemsetAsync(s->vel, 0, slab, s->stream), NBODY_MI355X_ERR_H2D, "memset vel");
+  HIP_TRY(hipMemsetAsync(s->mass, 0, sizeof(double) * static_cast<size_t>(s->slots), s->stream),
+          NBODY_MI355X_ERR_H2D, "memset mass");
+  int rc = nbody_mi355x_scene_fill_f64(sc, 0, s->n, s->pos[0], s->vel, s->mass, s->slots, s->stream);
+  if (rc != NBODY_MI355X_OK) return rc;
+  if (sc->scene == NBODY_MI355X_SCENE_PLUMMER) {  // into the centre-of-mass frame
+    double sums[6];
+    rc = nbody_mi355x_slab_sums_f64(s->pos[0], s->vel, s->n, s->slots, s->aos, s->stream);  // (aos: scratch here)
+    if (rc != NBODY_MI355X_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(sums, s->aos, sizeof sums, hipMemcpyDeviceToHost, s->stream), NBODY_MI355X_ERR_D2H,
+            "copy sums");
+    HIP_TRY(hipStreamSynchronize(s->stream), NBODY_MI355X_ERR_D2H, "generate sync");
+    for (double& v : sums) v /= static_cast<double>(s->n);
+    rc = nbody_mi355x_slab_shift_f64(s->pos[0], s->vel, s->n, s->slots, sums, s->stream);
+    if (rc != NBODY_MI355X_OK) return rc;
+  }
+  s->cur = 0;
+  s->acc_valid = false;
+  HIP_TRY(hipStreamSynchronize(s->stream), NBODY_MI355X_ERR_LAUNCH, "generate sync");
+  return NBODY_MI355X_OK;
+}
+
 extern "C" int nbody_mi355x_run(nbody_mi355x_sim* s, int64_t substeps, void* snapshot_out) {
   const int rc = nbody_mi355x_run_async(s, substeps, snapshot_out);
   return rc != NBODY_MI355X_OK ? rc : nbody_mi355x_wait(s);

@@ -15,7 +15,8 @@
 //       run a reference scene with its own step parameters (SUB divided by SUB_DIVISOR to
 //       shorten it) and write the text files the reference writes
 //   nbody_host_cli bench  IC N PATH [BIG] [SUB] [THREADS]
-//       IC = plummer | cube | ring (the library's portable generators, seed 42 / 7 / 42);
+//       IC = plummer | cube | ring (the library's portable generators, seed 42 / 7 / 42), or
+//       plummer-scale | cube-scale | ring-scale (one stream per body, made on all host threads);
 //       BIG big steps (default 3) of SUB small steps (default 5) through ParticleSimulation
 //       and the chosen Simulate path; one JSON line: Ginteractions/s from the host's own
 //       wall clock around every big step after the first (which holds the set-up), i.e.
@@ -214,6 +215,15 @@ int main(int argc, char** argv) {
     if (ic == "plummer") rc = nbody_mi355x_ic_plummer(n, 42, G, p.data(), m.data());
     else if (ic == "cube") { rc = nbody_mi355x_ic_uniform_cube(n, 7, G, p.data(), m.data()); dt = 1e-4; }
     else if (ic == "ring") { rc = nbody_mi355x_ic_ring(n, 42, 5.683e+26, 1.12e+8, 3.0e+7, 50, 50, 0.1, p.data(), m.data()); dt = 0.01; }
+    else if (ic == "plummer-scale" || ic == "cube-scale" || ic == "ring-scale") {
+      const std::vector<InPutParticle<double>> bodies = ic[0] == 'p' ? PlummerSphereAtScale(n) : ic[0] == 'c' ? UniformCubeAtScale(n) : RingAtScale(n);
+      rc = bodies.size() == static_cast<size_t>(n) ? NBODY_MI355X_OK : NBODY_MI355X_ERR_INVALID;
+      for (size_t i = 0; i < bodies.size(); i++) {
+        for (int c = 0; c < 3; c++) { p[6 * i + c] = bodies[i].particle.r[c]; p[6 * i + 3 + c] = bodies[i].particle.v[c]; }
+        m[i] = bodies[i].m;
+      }
+      dt = ic[0] == 'p' ? 1e-3 : ic[0] == 'c' ? 1e-4 : 0.01;
+    }
     else { fprintf(stderr, "unknown IC %s\n", ic.c_str()); return 2; }
     if (rc != NBODY_MI355X_OK) { fprintf(stderr, "%s\n", nbody_mi355x_last_error()); return 3; }
     ParticleSimulation<double, 4> sim(static_cast<int>(n), big, sub, dt, threads);

@@ -147,3 +147,52 @@ inline std::vector<InPutParticle<double>> Ring(int64_t n, uint64_t seed = 42, do
   }
   return out;
 }
+
+// ---- the same three scenes AT SCALE: one random stream per body, made on the
+// host's threads by nbody_mi355x_scene_host (the code nbody_mi355x_generate runs on the GPU).
+// Statistically the scenes above, not bit for bit.  The Plummer sphere is moved into its
+// centre-of-mass frame here, as PlummerSphere() is.
+inline std::vector<InPutParticle<double>> SceneAtScale(const nbody_mi355x_scene& scene) {
+  const size_t n = static_cast<size_t>(scene.num_particles > 0 ? scene.num_particles : 0);
+  std::vector<double> p(6 * n), m(n);
+  std::vector<InPutParticle<double>> out;
+  if (nbody_mi355x_scene_host(&scene, 0, scene.num_particles, p.data(), m.data()) != NBODY_MI355X_OK) return out;
+  double c[6] = {0, 0, 0, 0, 0, 0};
+  if (scene.scene == NBODY_MI355X_SCENE_PLUMMER) {
+    for (size_t i = 0; i < n; i++)
+      for (int k = 0; k < 6; k++) c[k] += p[6 * i + k];
+    for (double& v : c) v /= static_cast<double>(n);
+  }
+  out.resize(n);
+  for (size_t i = 0; i < n; i++) {
+    for (int k = 0; k < 3; k++) {
+      out[i].particle.r[k] = p[6 * i + k] - c[k];
+      out[i].particle.v[k] = p[6 * i + 3 + k] - c[3 + k];
+    }
+    out[i].m = m[i];
+  }
+  return out;
+}
+inline nbody_mi355x_scene SceneRecord(int32_t kind, int64_t n, uint64_t seed) {
+  nbody_mi355x_scene s{};
+  s.scene = kind;
+  s.seed = seed;
+  s.num_particles = n;
+  s.G = NBODY_MI355X_G_REFERENCE;
+  s.central_mass = 5.683e+26;  // saturn_ring.cc:42-63
+  s.ring_radius = 1.12e+8;
+  s.width_sigma = 3.0e+7;
+  s.thickness_sigma = 50;
+  s.v_sigma = 50;
+  s.mass_sigma = 0.1;
+  return s;
+}
+inline std::vector<InPutParticle<double>> PlummerSphereAtScale(int64_t n, uint64_t seed = 42) {
+  return SceneAtScale(SceneRecord(NBODY_MI355X_SCENE_PLUMMER, n, seed));
+}
+inline std::vector<InPutParticle<double>> UniformCubeAtScale(int64_t n, uint64_t seed = 7) {
+  return SceneAtScale(SceneRecord(NBODY_MI355X_SCENE_UNIFORM_CUBE, n, seed));
+}
+inline std::vector<InPutParticle<double>> RingAtScale(int64_t n, uint64_t seed = 42) {
+  return SceneAtScale(SceneRecord(NBODY_MI355X_SCENE_RING, n, seed));
+}

@@ -104,6 +104,11 @@ SYMBOLS = {
     "nbody_mi355x_ic_plummer": (C.c_int, [C.c_int64, C.c_uint64, C.c_double, _P, _P]),
     "nbody_mi355x_ic_uniform_cube": (C.c_int, [C.c_int64, C.c_uint64, C.c_double, _P, _P]),
     "nbody_mi355x_ic_ring": (C.c_int, [C.c_int64, C.c_uint64] + [C.c_double] * 6 + [_P, _P]),
+    "nbody_mi355x_scene_fill_f64": (C.c_int, [_P, C.c_int64, C.c_int64, _P, _P, _P, C.c_int64, _P]),
+    "nbody_mi355x_slab_sums_f64": (C.c_int, [_P, _P, C.c_int64, C.c_int64, _P, _P]),
+    "nbody_mi355x_slab_shift_f64": (C.c_int, [_P, _P, C.c_int64, C.c_int64, _P, _P]),
+    "nbody_mi355x_scene_host": (C.c_int, [_P, C.c_int64, C.c_int64, _P, _P]),
+    "nbody_mi355x_generate": (C.c_int, [_P, _P]),
 }
 
 _lib = None
@@ -207,6 +212,35 @@ def ic_ring(n: int, seed: int = 42, central_mass: float = 5.683e26, ring_radius:
     return p, m
 
 
+# scenes with one random stream per body: made on the device (Simulation.generate) or by the
+# same code on the host's threads (scene_host)
+SCENE_PLUMMER, SCENE_UNIFORM_CUBE, SCENE_RING = 0, 1, 2
+
+
+class Scene(C.Structure):
+    _fields_ = [("scene", C.c_int32), ("reserved", C.c_int32), ("seed", C.c_uint64), ("num_particles", C.c_int64),
+                ("G", C.c_double), ("central_mass", C.c_double), ("ring_radius", C.c_double),
+                ("width_sigma", C.c_double), ("thickness_sigma", C.c_double), ("v_sigma", C.c_double),
+                ("mass_sigma", C.c_double)]
+
+
+def make_scene(scene: int, n: int, seed: int = 42, G: float = G_REFERENCE, central_mass: float = 5.683e26,
+               ring_radius: float = 1.12e8, width_sigma: float = 3.0e7, thickness_sigma: float = 50.0,
+               v_sigma: float = 50.0, mass_sigma: float = 0.1) -> Scene:
+    """A scene record (ring defaults: the reference's saturn_ring.cc parameters)."""
+    return Scene(scene, 0, seed, n, G, central_mass, ring_radius, width_sigma, thickness_sigma, v_sigma, mass_sigma)
+
+
+def scene_host(scene: Scene, first: int = 0, count: int | None = None):
+    """Bodies [first, first + count) of the scene on the host's threads: (count,6) {r,v}, masses.
+    (A Plummer sphere is NOT moved into its centre-of-mass frame here: that needs every body.)"""
+    count = scene.num_particles - first if count is None else count
+    p = np.empty((count, 6), dtype=np.float64)
+    m = np.empty(count, dtype=np.float64)
+    check(lib().nbody_mi355x_scene_host(C.byref(scene), first, count, p.ctypes.data_as(_P), m.ctypes.data_as(_P)))
+    return p, m
+
+
 # ---------------------------------------------------------------- handle API
 class Simulation:
     """The handle API, as ParticleSimulation::SimulateMI355X() uses it:
@@ -232,6 +266,10 @@ class Simulation:
         p, pp = _np(np.asarray(particles).reshape(self.n, 6), self.host_dtype)
         m, mp = _np(np.asarray(mass).reshape(self.n), self.host_dtype)
         check(lib().nbody_mi355x_upload(self._h, pp, mp))
+
+    def generate(self, scene: Scene) -> None:
+        """The scene made on the device(s), straight into the handle's state, instead of upload()."""
+        check(lib().nbody_mi355x_generate(self._h, C.byref(scene)))
 
     def run(self, substeps: int, snapshot: bool = True):
         """One big step.  Returns DeviceOutputParticle[n] as (n,9) {r,v,a*G} or None."""

@@ -39,8 +39,8 @@ import ctypes as C
 import numpy as np
 import torch
 
-from . import (EULER, FP64, G_REFERENCE, KDK, KICK_DRIFT, SYM_VARIANTS, TILE, VARIANT_SYM, VARIANT_SYM8, VARIANT_SYMW8,
-               StepArgs, check, lib, round_up)
+from . import (EULER, FP64, G_REFERENCE, KDK, KICK_DRIFT, SCENE_PLUMMER, SYM_VARIANTS, TILE, VARIANT_SYM, VARIANT_SYM8,
+               VARIANT_SYMW8, Scene, StepArgs, check, lib, round_up)
 
 SYM_MIN_BODIES = 2048  # as kSymMinBodies in csrc/nbody_kernels.hip
 
@@ -109,6 +109,24 @@ class HipBackend:
         stream = torch.cuda.current_stream(pos_cur.device).cuda_stream
         check(self._lib.nbody_mi355x_step_f64(C.byref(a), C.c_void_p(stream)))
 
+    def scene_fill(self, scene, first, count, pos_slab, vel, mass_slab, S):
+        """Bodies [first, first + count) of the scene into one slab (nbody_mi355x_scene_fill_f64)."""
+        stream = torch.cuda.current_stream(pos_slab.device).cuda_stream
+        check(self._lib.nbody_mi355x_scene_fill_f64(C.byref(scene), first, count, C.c_void_p(pos_slab.data_ptr()),
+                                                    C.c_void_p(vel.data_ptr()) if vel is not None else None,
+                                                    C.c_void_p(mass_slab.data_ptr()), S, C.c_void_p(stream)))
+
+    def slab_sums(self, pos_slab, vel, count, S, sums6):
+        stream = torch.cuda.current_stream(pos_slab.device).cuda_stream
+        check(self._lib.nbody_mi355x_slab_sums_f64(C.c_void_p(pos_slab.data_ptr()), C.c_void_p(vel.data_ptr()), count, S,
+                                                   C.c_void_p(sums6.data_ptr()), C.c_void_p(stream)))
+
+    def slab_shift(self, pos_slab, vel, count, S, shift6):
+        stream = torch.cuda.current_stream(pos_slab.device).cuda_stream
+        check(self._lib.nbody_mi355x_slab_shift_f64(C.c_void_p(pos_slab.data_ptr()),
+                                                    C.c_void_p(vel.data_ptr()) if vel is not None else None, count, S,
+                                                    (C.c_double * 6)(*shift6), C.c_void_p(stream)))
+
     def kdk_drift(self, *, pos_cur, pos_next, vel, kdk_acc, S, world, rank, count, dt, G):
         """First half of a leapfrog small step for the own slab (nbody_mi355x_kdk_drift_f64)."""
         a = StepArgs()
@@ -123,9 +141,13 @@ class ShardedNBody:
     def __init__(self, particles, mass, dt, *, rank=0, world=1, device="cuda", G=G_REFERENCE, eps2=0.0,
                  backend=None, overlap=True, group=None, use_workspace=True, force_collectives=False,
                  integrator=EULER):
-        particles = np.ascontiguousarray(particles, dtype=np.float64).reshape(-1, 6)
-        mass = np.ascontiguousarray(mass, dtype=np.float64)
-        self.n, self.rank, self.world = particles.shape[0], rank, world
+        # `particles`: an (n, 6) array {r, v} with `mass` (n,), uploaded; or a Scene record
+        # (mass = None): every rank then makes the bodies it holds on its own device
+        scene = particles if isinstance(particles, Scene) else None
+        if scene is None:
+            particles = np.ascontiguousarray(particles, dtype=np.float64).reshape(-1, 6)
+            mass = np.ascontiguousarray(mass, dtype=np.float64)
+        self.n, self.rank, self.world = (scene.num_particles if scene is not None else particles.shape[0]), rank, world
         self.dt, self.G, self.eps2 = float(dt), float(G), float(eps2)
         self.overlap, self.group = overlap, group
         if integrator not in (EULER, KICK_DRIFT, KDK):
@@ -147,21 +169,23 @@ class ShardedNBody:
             unit = max(unit, 512)
         self.S = S = round_up(big, unit)
 
-        # host image of the slab layout; padding slots: mass 0 at the origin
-        pos = np.zeros((world, 3, S))
-        m = np.zeros((world, S))
-        for r in range(world):
-            b, c = self.begins[r], self.counts[r]
-            pos[r, :, :c] = particles[b:b + c, :3].T
-            m[r, :c] = mass[b:b + c]
-        vel = np.zeros((3, S))
-        b, c = self.begins[rank], self.count
-        vel[:, :c] = particles[b:b + c, 3:].T
-
         dev = self.device
-        self.pos = [torch.from_numpy(pos).to(dev), torch.from_numpy(pos.copy()).to(dev)]
-        self.mass = torch.from_numpy(m).to(dev)
-        self.vel = torch.from_numpy(vel).to(dev)
+        if scene is None:
+            # host image of the slab layout; padding slots: mass 0 at the origin
+            pos = np.zeros((world, 3, S))
+            m = np.zeros((world, S))
+            for r in range(world):
+                b, c = self.begins[r], self.counts[r]
+                pos[r, :, :c] = particles[b:b + c, :3].T
+                m[r, :c] = mass[b:b + c]
+            vel = np.zeros((3, S))
+            b, c = self.begins[rank], self.count
+            vel[:, :c] = particles[b:b + c, 3:].T
+            self.pos = [torch.from_numpy(pos).to(dev), torch.from_numpy(pos.copy()).to(dev)]
+            self.mass = torch.from_numpy(m).to(dev)
+            self.vel = torch.from_numpy(vel).to(dev)
+        else:
+            self._generate(scene)
         self.acc = torch.zeros((3, S), dtype=torch.float64, device=dev)
         self.snap = torch.zeros((max(self.count, 1), 9), dtype=torch.float64, device=dev)
         # pair-symmetric kernels: used when the backend offers them, the
@@ -189,6 +213,33 @@ class ShardedNBody:
         self._send = self._recv = None
         self.cur = 0
         self._fresh = True  # every slab of pos[cur] is current (true right after upload)
+
+    def _generate(self, scene):
+        """The scene made on this rank's device: every slab's positions and masses (O(N) per
+        rank, no exchange), the own slab's velocities.  A Plummer sphere goes into its
+        centre-of-mass frame: own-slab sums, one all-reduce of 6 doubles, a shift."""
+        dev, S, P = self.device, self.S, self.world
+        self.pos = [torch.zeros((P, 3, S), dtype=torch.float64, device=dev)]
+        self.mass = torch.zeros((P, S), dtype=torch.float64, device=dev)
+        self.vel = torch.zeros((3, S), dtype=torch.float64, device=dev)
+        for r in range(P):
+            self.backend.scene_fill(scene, self.begins[r], self.counts[r], self.pos[0][r],
+                                    self.vel if r == self.rank else None, self.mass[r], S)
+        if scene.scene == SCENE_PLUMMER:
+            sums = torch.zeros(6, dtype=torch.float64, device=dev)
+            self.backend.slab_sums(self.pos[0][self.rank], self.vel, self.count, S, sums)
+            if P > 1:
+                import torch.distributed as dist
+                if dist.get_backend(self.group) == "nccl":
+                    dist.all_reduce(sums, group=self.group)
+                else:                      # gloo rehearsal: staged through the host
+                    host = sums.cpu()
+                    dist.all_reduce(host, group=self.group)
+                    sums = host
+            shift = (sums.cpu().numpy() / self.n).tolist()
+            for r in range(P):
+                self.backend.slab_shift(self.pos[0][r], self.vel if r == self.rank else None, self.counts[r], S, shift)
+        self.pos.append(self.pos[0].clone())
 
     # ------------------------------------------------------------------ one small step
     def step(self, snapshot=False):

@@ -177,7 +177,7 @@ def test_symmetric_phases_equal_whole(variant):
     assert whole.abs().max() > 0
 
 
-def _rank_main(rank, world, port, n, steps, q, integrator=0):
+def _rank_main(rank, world, port, n, steps, q, integrator=0, scene_kind=None):
     """A real rank of the sharded driver (own process, own process group); the two ranks
     share the one GPU of the test box and talk over gloo, staged through the host."""
     import os
@@ -194,7 +194,10 @@ def _rank_main(rank, world, port, n, steps, q, integrator=0):
     try:
         import nbody_mi355x as nb
         from nbody_mi355x.sharded import ShardedNBody
-        p, m = nb.ic_plummer(n, 31)
+        if scene_kind is None:
+            p, m = nb.ic_plummer(n, 31)
+        else:                              # made on the device by every rank, no host arrays
+            p, m = nb.make_scene(scene_kind, n, seed=31), None
         sim = ShardedNBody(p, m, 1e-3, rank=rank, world=world, device="cuda:0", overlap=True, integrator=integrator)
         for k in range(steps):
             sim.step(snapshot=(k == steps - 1))
@@ -275,6 +278,39 @@ def test_real_ranks_other_integrators(n, expect_sym, world, integrator):
     # ... and it is not the Euler step: the integrators differ at O(dt^2) per step
     euler, _ = ol.simulate(p, m, 1, steps, 1e-3, threads=16)
     assert rel_pos_err(state[:, :3], euler[:, :3]) > 1e-9
+
+
+@pytest.mark.parametrize("kind,n,world", [(0, 20000, 2), (0, 1500, 3), (2, 20000, 2)])
+def test_real_ranks_make_their_scene_on_the_device(kind, n, world):
+    """ShardedNBody given a Scene record instead of arrays: every rank fills the slabs it
+    holds on its own device (one random stream per body), the Plummer sphere's centre of mass
+    goes through one all-reduce of 6 doubles.  Against the C handle's generate() + run()."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    steps = 4
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rank_main, args=(r, world, port, n, steps, q, 0, kind)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    res = sorted((q.get(timeout=100) for _ in range(world)), key=lambda t: t[0])
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    with nb.Simulation(n, 1e-3) as sim:
+        sim.generate(nb.make_scene(kind, n, seed=31))
+        first = sim.download()
+        out = sim.run(steps, snapshot=True)
+        fin = sim.download()
+    state = np.concatenate([r[1] for r in res])
+    snap = np.concatenate([r[2] for r in res])
+    # (the centre of mass is summed in another order: 1e-16 of the sphere's size)
+    assert np.abs(state[:, :3] - fin[:, :3]).max() <= 1e-12 * np.abs(fin[:, :3]).max()
+    assert np.abs(snap[:, 3:6] - out[:, 3:6]).max() <= 1e-11 * np.abs(out[:, 3:6]).max()
+    assert np.abs(fin[:, :3] - first[:, :3]).max() > 0
 
 
 def _rccl_single_rank_main(port, n, steps, q):

@@ -218,7 +218,8 @@ def _cli_bench(*args):
 def test_cli_bench_on_host_paths():
     """`nbody_host_cli bench`: the C++ bench driver (CLI args instead of the
     reference's constexpr locals) over the library's scene generators."""
-    for ic, path in [("plummer", "avx2"), ("ring", "cpu"), ("cube", "avx2")]:
+    for ic, path in [("plummer", "avx2"), ("ring", "cpu"), ("cube", "avx2"),
+                     ("plummer-scale", "avx2"), ("ring-scale", "cpu"), ("cube-scale", "avx2")]:   # *-scale: one stream per body
         line, _ = _cli_bench(ic, 1024, path, 3, 2, 4)
         assert line["bodies"] == 1024 and line["big_steps_timed"] == 2 and line["substeps"] == 2
         assert line["Ginteractions_per_s"] > 0
