@@ -376,7 +376,9 @@ int nbody_mi355x_scene_host(const nbody_mi355x_scene* scene, int64_t first, int6
                             double* particles, double* mass);
 /* Level 2: the whole scene straight into the handle's device state, in place of upload()
  * (scene->num_particles must be the handle's); on a multi-device handle every device makes
- * the bodies it holds.  PLUMMER: centre of mass and mean velocity are removed. */
+ * the bodies it holds.  PLUMMER: centre of mass and mean velocity are removed.  A scene that
+ * is refused (unknown, wrong size, bad parameters) leaves the state as it was; after any other
+ * error the state is undefined: generate or upload again. */
 int nbody_mi355x_generate(nbody_mi355x_sim* sim, const nbody_mi355x_scene* scene);
 
 #ifdef __cplusplus

@@ -288,7 +288,12 @@ extern "C" int nbody_mi355x_scene_host(const nbody_mi355x_scene* sc, int64_t fir
   const int64_t per = (count + threads - 1) / threads;
   for (int64_t t = 1; t < threads; t++) {
     const int64_t lo = t * per, hi = lo + per < count ? lo + per : count;
-    if (lo < hi) pool.emplace_back(work, lo, hi);
+    if (lo >= hi) continue;
+    try {
+      pool.emplace_back(work, lo, hi);
+    } catch (...) {  // no more threads to be had: no exception crosses the C ABI, the range is done here
+      work(lo, hi);
+    }
   }
   work(0, per < count ? per : count);
   for (std::thread& t : pool) t.join();
