@@ -62,6 +62,13 @@ __global__ __launch_bounds__(256) void k(float* out, float seed) {
       if (KIND == 25) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(p[i]) : "v"(pm), "v"(pc));
       if (KIND == 26) asm volatile("v_sub_f32 %0, %1, %0" : "+v"(a[i]) : "s"(m));
       if (KIND == 27) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(a[i]) : "s"(m), "v"(c));
+      if (KIND == 28) asm volatile("v_cvt_f32_f64 %0, %1" : "=v"(a[i]) : "v"(d[i]));
+      if (KIND == 29) asm volatile("v_cvt_f64_f32 %0, %1" : "=v"(d[i]) : "v"(a[i]));
+      if (KIND == 30) asm volatile("v_min3_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(m), "v"(c));
+      if (KIND == 31) asm volatile("v_ldexp_f64 %0, %0, %1" : "+v"(d[i]) : "v"(it));
+      if (KIND == 32) asm volatile("v_rcp_f64 %0, %0" : "+v"(d[i]));
+      if (KIND == 33) asm volatile("v_sqrt_f64 %0, %0" : "+v"(d[i]));
+      if (KIND == 34) asm volatile("v_rcp_f32 %0, %0" : "+v"(a[i]));
     }
   }
   float s = 0;
@@ -120,6 +127,13 @@ int main() {
     run<25>("v_pk_fma_f32 acc=addend", 1, out, w);
     run<26>("v_sub_f32 sgpr src", 1, out, w);
     run<27>("v_fmac_f32 sgpr src", 1, out, w);
+    run<28>("v_cvt_f32_f64", 1, out, w);
+    run<29>("v_cvt_f64_f32", 1, out, w);
+    run<30>("v_min3_f32", 1, out, w);
+    run<31>("v_ldexp_f64", 1, out, w);
+    run<32>("v_rcp_f64", 1, out, w);
+    run<33>("v_sqrt_f64", 1, out, w);
+    run<34>("v_rcp_f32", 1, out, w);
   }
   hipFree(out);
   return 0;
