@@ -23,6 +23,20 @@ Extra objects in the line:
                 build container into oracle/_ref/libnbody_ref.so; kind "reference"), or
                 the oracle's restatement of it (kind "port") when that file is absent,
                 on this host's cores, on a bounded sample.  N=1 only, rank 0 only.
+With more than one rank (or --force-collectives) the line also proves what ran:
+  collectives   what the communicator itself reports: backend, world size as
+                torch.distributed sees it, RCCL version, every rank's device (name, ordinal,
+                PCI bus id) -- gathered THROUGH the communicator
+  per_rank_ms_per_step   every rank's own wall clock over the K timed steps
+  collective_ms the two collectives of a step (all-gather of positions, reduce-scatter of
+                partial sums), timed on their own after the timed region, max over ranks
+  verify        (default at N > 1, --verify at N = 1; after the timed region, never inside)
+                one more step whose accelerations are checked on 1024 sampled bodies against
+                the oracle's exact sums (the checker, tests/oracle_lib.py), total momentum
+                change ~ 0, and the positions of all bodies against ONE GPU running the same
+                steps through the handle API (max relative difference <= 1e-12, SURVEY 8d
+                config 4) or against a --reference-checksum file a one-GPU run wrote.
+                A failed check makes the exit code non-zero.
 """
 import argparse
 import json
@@ -85,6 +99,43 @@ def _timed_runs(sim, substeps, reps):
     return sorted(times)
 
 
+def config2_cpu_side(p, m, dt, small_steps=4000):
+    """BASELINE config 2 is "SimulateMI355X() on 1 GPU vs SimulateAVX2()" (ref: saturn_ring.cc:70):
+    the CPU side of it on this host, same scene (the golden fixture's ICs), all threads of the
+    GPU's CPU share -- the REAL reference's SimulateAVX2() (oracle/_ref, a thread spawned per
+    small step as the reference does, particle_simulation.h:355-366) and this repository's host
+    mirror of it (persistent worker pool), through nbody_host_cli.  Part of the cpu_baseline leg."""
+    import subprocess
+    import tempfile
+    import numpy as np
+    import oracle_lib as ol
+    threads = max(1, min(THREAD_CAP, os.cpu_count() or 1))
+    out = {"cpu_threads": threads, "cpu_small_steps": small_steps}
+    if ol.have_ref():
+        _, sec = ol.ref_simulate(p, m, 1, small_steps, dt, threads=threads, mode="avx2")
+        out["reference_avx2_us_per_small_step"] = round(sec / small_steps * 1e6, 3)
+    cli = REPO / "n-body-sim_amd" / "host" / "nbody_host_cli"
+    if cli.exists():
+        try:
+            with tempfile.TemporaryDirectory() as tmp:
+                ics = Path(tmp) / "ics.bin"
+                with open(ics, "wb") as f:
+                    f.write(np.int64(p.shape[0]).tobytes())
+                    f.write(np.ascontiguousarray(p, dtype=np.float64).tobytes())
+                    f.write(np.ascontiguousarray(m, dtype=np.float64).tobytes())
+                r = subprocess.run([str(cli), "run", "avx2", str(ics), "2", str(small_steps), repr(dt), str(threads),
+                                    str(Path(tmp) / "out.bin")], capture_output=True, text=True, timeout=300)
+            line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            if r.returncode == 0 and line:
+                sec = json.loads(line[-1])["big_step_seconds"][1]     # (the first big step holds the pool's start)
+                out["host_mirror_avx2_us_per_small_step"] = round(sec / small_steps * 1e6, 3)
+            else:
+                out["host_mirror_avx2_error"] = (r.stderr or "no result line").strip()[-200:]
+        except Exception as e:  # noqa: BLE001
+            out["host_mirror_avx2_error"] = f"{type(e).__name__}: {e}"
+    return out
+
+
 def other_configs(nb):
     """The other BASELINE.json configs on ONE GPU, beside the headline (config 4): bounded to
     well under a minute of GPU time.  All through the handle API (create / upload / run), the
@@ -104,6 +155,7 @@ def other_configs(nb):
     out["config2_saturn_ring_n500_fp64"] = {"us_per_small_step": round(t[1] / 21600 * 1e6, 3), "small_steps": 21600,
                                             "repetitions": 3, "statistic": "median",
                                             "kernel": "step_wave_kernel, hipGraph replay of 64 small steps"}
+    out["config2_saturn_ring_n500_fp64"].update(config2_cpu_side(p, m, dt))
     # config 3: Plummer N = 65 536 fp64 ("single-GPU roofline")
     n = 65536
     p, m = nb.ic_plummer(n, 42)
@@ -144,6 +196,151 @@ def other_configs(nb):
             "value": round(g, 1), "unit": "Ginteractions/s", "frac": frac(g, prec),
             "ms_per_step": round(0.5 * (t[0] + t[1]) * 1e3, 2), "repetitions": 2, "statistic": "mean"}
     return out
+
+
+VERIFY_ROWS = 1024
+VERIFY_TOL = {"f64": {"rows": 1e-12, "momentum": 1e-12, "positions": 1e-12},
+              "f32": {"rows": 1e-4, "momentum": 1e-5, "positions": 1e-4}}
+
+
+def sampled_rows(n, count=VERIFY_ROWS, seed=0):
+    """The bodies whose accelerations are checked: the same on every rank."""
+    import numpy as np
+    return np.sort(np.random.default_rng(seed).choice(n, min(count, n), replace=False))
+
+
+def rows_of_rank(rows, begin, count):
+    """Which of the sampled bodies a rank owns: (their positions in `rows`, their local indices)."""
+    import numpy as np
+    sel = np.nonzero((rows >= begin) & (rows < begin + count))[0]
+    return sel, rows[sel] - begin
+
+
+def check_rows(a_gpu, a_ref, tol):
+    """Sampled-row accelerations against the checker's: the largest vector difference over the
+    largest acceleration of the sample (the metric of tests/test_gpu_parity.py)."""
+    import numpy as np
+    err = float(np.linalg.norm(a_gpu - a_ref, axis=1).max() / np.linalg.norm(a_ref, axis=1).max())
+    worst = float((np.linalg.norm(a_gpu - a_ref, axis=1) / np.linalg.norm(a_ref, axis=1)).max())
+    return {"max_err_over_max_acc": err, "max_rel_err": worst, "tol": tol, "ok": bool(err <= tol)}
+
+
+def check_momentum(f_parts, scale_parts, tol):
+    """sum_i m_i a_i over ALL bodies (added rank by rank) against sum_i m_i |a_i|: Newton's third
+    law -- a size-independent property of a correct force sum, whatever the number of ranks."""
+    import numpy as np
+    f = np.sum(np.asarray(f_parts, dtype=np.float64), axis=0)
+    scale = float(np.sum(scale_parts))
+    rel = float(np.linalg.norm(f) / scale) if scale > 0 else float("inf")
+    return {"rel_net_force": rel, "tol": tol, "ok": bool(rel <= tol)}
+
+
+def check_positions(pos, pos_ref, tol):
+    """max_i |dr_i| / |r_i| (vector norms) between two runs of the same steps."""
+    import numpy as np
+    if pos.shape != pos_ref.shape:
+        return {"ok": False, "error": f"shape {pos.shape} against {pos_ref.shape}"}
+    den = np.linalg.norm(pos_ref, axis=1)
+    den = np.where(den == 0, 1.0, den)
+    err = float((np.linalg.norm(pos - pos_ref, axis=1) / den).max())
+    return {"max_rel_position_diff": err, "tol": tol, "ok": bool(err <= tol)}
+
+
+def verify_run(args, sim, nb, dist, world, rank, steps_done, ics, dt, prec, integrator):
+    """After the timed region: see `verify` in the module docstring.  Collective (every rank
+    calls it); the result dict is returned on rank 0, None elsewhere."""
+    import numpy as np
+    n = sim.n
+    tol = VERIFY_TOL["f64" if prec == nb.FP64 else "f32"]
+    use_dist = dist is not None and dist.is_initialized()
+    masses = sim.all_masses()                    # (n,) host copy of what the device holds
+    pos_before = sim.all_positions()             # every slab made current first (collective)
+    sim.step(snapshot=True)
+    snap = sim.own_snapshot()                    # own bodies: {r', v', a G} at pos_before
+    begin, count = sim.begins[rank], sim.count
+    rows = sampled_rows(n)
+    sel, local = rows_of_rank(rows, begin, count)
+    mine = {"sel": sel, "acc": snap[local, 6:9],
+            "f": (masses[begin:begin + count, None] * snap[:, 6:9]).sum(0),
+            "scale": float((masses[begin:begin + count] * np.linalg.norm(snap[:, 6:9], axis=1)).sum())}
+    parts = [None] * world
+    if use_dist:
+        dist.all_gather_object(parts, mine)
+    else:
+        parts = [mine]
+    pos_after = sim.all_positions()              # collective
+    if rank != 0:
+        return None
+    import oracle_lib as ol                      # the CHECKER (tests/): never on the timed path
+    out = {"steps_before": steps_done, "sampled_rows": int(len(rows))}
+    a_gpu = np.zeros((len(rows), 3))
+    for part in parts:
+        a_gpu[part["sel"]] = part["acc"]
+    state = np.zeros((n, 6))
+    state[:, :3] = pos_before
+    threads = max(1, min(THREAD_CAP, os.cpu_count() or 1))
+    out["rows_vs_oracle"] = check_rows(a_gpu, ol.accel_rows(state, masses, rows, threads=threads), tol["rows"])
+    out["momentum"] = check_momentum([q["f"] for q in parts], [q["scale"] for q in parts], tol["momentum"])
+    total = steps_done + 1
+    if args.write_checksum:
+        np.save(args.write_checksum, pos_after)
+        out["checksum_written"] = {"file": str(args.write_checksum), "steps": total}
+    if args.reference_checksum:
+        out["positions_vs_reference_file"] = dict(check_positions(pos_after, np.load(args.reference_checksum), tol["positions"]),
+                                                  file=str(args.reference_checksum))
+    # the same steps on ONE GPU through the handle API (what SimulateMI355X() runs), when the
+    # ICs are host arrays and the re-run fits the budget
+    est = total * float(n) * float(n) / 2.5e12
+    if ics is not None and (world > 1 or args.force_collectives) and est <= args.verify_budget_s:
+        with nb.Simulation(n, dt, precision=prec, integrator=integrator, device=sim.device.index or 0) as one:
+            one.upload(*ics)
+            if integrator == nb.KDK:              # (the sharded driver's leapfrog steps are whole steps)
+                for _ in range(total):
+                    one.run(1, snapshot=False)
+            else:
+                one.run(total, snapshot=False)
+            ref = one.download()[:, :3]
+        out["positions_vs_one_gpu"] = dict(check_positions(pos_after, ref, tol["positions"]), steps=total)
+    elif ics is not None and (world > 1 or args.force_collectives):
+        out["positions_vs_one_gpu"] = {"skipped": f"estimated {est:.0f} s > --verify-budget-s {args.verify_budget_s:g}"}
+    out["ok"] = all(v.get("ok", True) for v in out.values() if isinstance(v, dict))
+    return out
+
+
+def time_collectives(sim, dist, torch, world, reps=5):
+    """The two collectives of a small step on their own, after the timed region: HIP events on
+    the launch stream around each blocking call (the stream waits for RCCL's), max over ranks."""
+    t = sim.time_collectives(reps)
+    if t is None:
+        return None
+    if world > 1:
+        parts = [None] * world
+        dist.all_gather_object(parts, t)
+        for key in ("all_gather", "reduce_scatter"):
+            vals = [q[key] for q in parts if q.get(key) is not None]
+            t[key] = max(vals) if vals else None
+    return {k: (round(v, 4) if isinstance(v, float) else v) for k, v in t.items()}
+
+
+def describe_collectives(torch, dist, world, backend, dev_index):
+    """What the communicator reports, gathered through it."""
+    props = torch.cuda.get_device_properties(dev_index)
+    me = {"rank": dist.get_rank(), "device_index": dev_index, "name": props.name,
+          "pci_bus_id": getattr(props, "pci_bus_id", None), "uuid": str(getattr(props, "uuid", "")) or None,
+          "pid": os.getpid(), "host": os.uname().nodename}
+    devices = [None] * dist.get_world_size()
+    dist.all_gather_object(devices, me)
+    ver = None
+    if backend == "nccl":
+        try:
+            ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception as e:  # noqa: BLE001
+            ver = f"unavailable ({e})"
+    return {"backend": dist.get_backend(), "is_rccl": backend == "nccl", "world_size_seen": dist.get_world_size(),
+            "world_size_env": world, "rccl_version": ver, "hip": getattr(torch.version, "hip", None),
+            "distinct_devices": len({(d["host"], d["pci_bus_id"], d["device_index"]) for d in devices}),
+            "devices": devices}
+
 
 
 def _cpu_model():
@@ -256,6 +453,16 @@ def main():
     ap.add_argument("--force-collectives", action="store_true",
                     help="rehearsal only: with one rank, still take the multi-rank code path (RCCL "
                          "all-gather + reduce-scatter over a world of 1, split steps)")
+    ap.add_argument("--verify", dest="verify", action="store_true", default=None,
+                    help="after the timed region: sampled rows against the oracle, momentum, positions against "
+                         "one GPU (default with more than one rank; see the module docstring)")
+    ap.add_argument("--no-verify", dest="verify", action="store_false")
+    ap.add_argument("--write-checksum", type=Path, default=None,
+                    help="with verification: save the positions after the verified step (.npy) for --reference-checksum")
+    ap.add_argument("--reference-checksum", type=Path, default=None,
+                    help="with verification: positions a ONE-GPU run of the same command wrote with --write-checksum")
+    ap.add_argument("--verify-budget-s", type=float, default=90.0,
+                    help="skip the one-GPU re-run of the verification when it would take longer than this")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -302,10 +509,15 @@ def main():
         (p, m), dt, scene = nb.ic_plummer(n, 42), 1e-3, f"plummer_sphere_n{n}_{args.precision}_seed42_dt1e-3"
     else:
         (p, m), dt, scene = nb.ic_uniform_cube(n, 7), 1e-4, f"uniform_cube_n{n}_{args.precision}_seed7_dt1e-4"
+    integrator = {"euler": nb.EULER, "kick_drift": nb.KICK_DRIFT, "kdk": nb.KDK}[args.integrator]
     sim = ShardedNBody(p, m, dt, rank=rank, world=world, device=device,
                        backend=HipBackend(precision=prec, variant=args.variant),
                        overlap=not args.no_overlap, force_collectives=args.force_collectives,
-                       integrator={"euler": nb.EULER, "kick_drift": nb.KICK_DRIFT, "kdk": nb.KDK}[args.integrator])
+                       integrator=integrator)
+    explicit_verify = args.verify is True
+    do_verify = (world > 1) if args.verify is None else args.verify
+    # the one-GPU re-run of the verification starts from the same host arrays (rank 0 only)
+    ics = (p, m) if (do_verify and rank == 0 and not args.device_ics) else None
     del p, m
 
     def barrier():
@@ -331,10 +543,32 @@ def main():
     dev_s = evs[0].elapsed_time(evs[K]) * 1e-3
     per_step = sorted(evs[k].elapsed_time(evs[k + 1]) * 1e-3 for k in range(K))
     med_s = per_step[K // 2] if K % 2 else 0.5 * (per_step[K // 2 - 1] + per_step[K // 2])
+    own_wall = wall
     if world > 1:
         t = torch.tensor([wall, dev_s, med_s], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall, dev_s, med_s = float(t[0]), float(t[1]), float(t[2])
+
+    # ---- after the timed region: what proves a multi-rank run (nothing here is timed into `value`)
+    proof = {}
+    if use_dist:
+        proof["collectives"] = describe_collectives(torch, dist, world, args.backend, dev_index)
+        walls = [None] * world
+        dist.all_gather_object(walls, own_wall)
+        proof["per_rank_ms_per_step"] = [round(w / K * 1e3, 3) for w in walls]
+        proof["collective_ms"] = time_collectives(sim, dist, torch, world)
+    verify_failed = False
+    if do_verify:
+        try:
+            v = verify_run(args, sim, nb, dist if use_dist else None, world, rank, W + K, ics, dt, prec, integrator)
+        except Exception as e:  # noqa: BLE001  (an unusable checker is reported, a failed check is fatal)
+            if explicit_verify:
+                raise
+            v = {"ok": None, "error": f"{type(e).__name__}: {e}"}
+        if rank == 0:
+            proof["verify"] = v
+            verify_failed = v.get("ok") is False
+    del ics
 
     if rank == 0:
         inter_per_step = float(n) * float(n)
@@ -369,10 +603,12 @@ def main():
             "vs_baseline": None, "dtype": "f64" if prec == nb.FP64 else "f32", "data": "synthetic",
             "config": {"workload": scene,
                        "bodies": n, "interactions_per_step": inter_per_step,
-                       "parallelism": (f"i-shard x{world}, {'RCCL' if args.backend == 'nccl' else args.backend + ' (rehearsal, host-staged)'} all-gather of positions"
+                       "parallelism": ("one GPU, no collective" if not use_dist else
+                                       f"i-shard x{world}, {'RCCL' if args.backend == 'nccl' else args.backend + ' (rehearsal, host-staged)'} all-gather of positions"
                                        + (" + reduce-scatter of pair-symmetric partial sums" if sim.acc_all is not None else "")
                                        + " per step"
-                                       + ("" if args.no_overlap or world == 1 else ", all-gather overlapped with the own-slab part")),
+                                       + ("" if args.no_overlap else ", all-gather overlapped with the own-slab part")
+                                       + (" (one rank: --force-collectives rehearsal)" if world == 1 else "")),
                        "kernel": kernel_label,
                        "kernel_variant": args.variant, "integrator": args.integrator},
             "roofline": {"bound": "valu_fp64" if prec == nb.FP64 else "valu_fp32", "achieved": round(ach, 3),
@@ -393,6 +629,7 @@ def main():
                                 "value": round(inter_per_step / med_s / 1e9, 2),
                                 "min_ms": round(per_step[0] * 1e3, 3), "max_ms": round(per_step[-1] * 1e3, 3)},
         }
+        line.update(proof)
         headline = (world == 1 and n == 1048576 and args.ic == "plummer" and prec == nb.FP64 and args.variant == 0
                     and not args.force_collectives)
         if headline and not args.no_other_configs:
@@ -407,8 +644,15 @@ def main():
         os.dup2(2, 1)
 
     if use_dist:
+        failed = torch.tensor([1 if verify_failed else 0], dtype=torch.int32,
+                              device=device if args.backend == "nccl" else "cpu")
+        if world > 1:
+            dist.broadcast(failed, src=0)            # every rank leaves with rank 0's verdict
+        verify_failed = bool(int(failed[0]))
         dist.barrier()
         dist.destroy_process_group()
+    if verify_failed:
+        sys.exit("bench.py: verification FAILED (see `verify` in the line)" if rank == 0 else 1)
 
 
 if __name__ == "__main__":

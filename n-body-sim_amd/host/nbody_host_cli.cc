@@ -10,7 +10,8 @@
 //   nbody_host_cli run    PATH IN.bin BIG SUB DT THREADS OUT.bin
 //       PATH = cpu | avx2 | avx512 | mi355x | mi355x-fp32 | mi355x-shardsK | cpu-f32 | avx512-f32 | mi355x-f32host
 //       read IN.bin (format above), simulate BIG big steps of SUB small steps, write
-//       OutPutParticle rows double[(BIG+1)][n][11] {r,v,a,m,t} (float runs are widened)
+//       OutPutParticle rows double[(BIG+1)][n][11] {r,v,a,m,t} (float runs are widened); one JSON
+//       line on stdout with the host's wall clock of every big step
 //   nbody_host_cli demo   NAME PATH [BIG] [SUB_DIVISOR] [OUTDIR]
 //       run a reference scene with its own step parameters (SUB divided by SUB_DIVISOR to
 //       shorten it) and write the text files the reference writes
@@ -154,6 +155,12 @@ int RunRaw(const std::string& path, const std::vector<double>& p, const std::vec
   const std::string status = Simulate(sim, path);
   fprintf(stderr, "%s\n", status.c_str());
   if (status != "ok" && status.find("succesfull") == std::string::npos) return 3;
+  // one JSON line: the host's own wall clock around every big step (the reference's
+  // execution_time_, particle_simulation.h:203-207); the first one holds the set-up
+  printf("{\"path\": \"%s\", \"bodies\": %d, \"substeps\": %lld, \"threads\": %d, \"big_step_seconds\": [", path.c_str(), n,
+         (long long)sub, threads);
+  for (int64_t k = 0; k < big; k++) printf("%s%.9f", k ? ", " : "", sim.BigStepSeconds()[k]);
+  printf("]}\n");
   FILE* f = fopen(out_path, "wb");
   if (!f) return 4;
   for (const auto& snap : sim.OutputData())

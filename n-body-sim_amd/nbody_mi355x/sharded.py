@@ -39,10 +39,46 @@ import ctypes as C
 import numpy as np
 import torch
 
-from . import (EULER, FP64, G_REFERENCE, KDK, KICK_DRIFT, SCENE_PLUMMER, SYM_VARIANTS, TILE, VARIANT_SYM, VARIANT_SYM8,
-               VARIANT_SYMW8, Scene, StepArgs, check, lib, round_up)
+from . import (EULER, FP64, G_REFERENCE, KDK, KICK_DRIFT, SCENE_PLUMMER, SYM_VARIANTS, TILE, VARIANT_SYM, Scene, StepArgs,
+               check, lib, round_up)
 
 SYM_MIN_BODIES = 2048  # as kSymMinBodies in csrc/nbody_kernels.hip
+
+
+class _Range:
+    """A named range in a rocprofv3 trace (--marker-trace): torch.cuda.nvtx is roctx on ROCm
+    builds.  The reference's only timing hooks are wall-clock timers around a big step
+    (particle_simulation.h:203-207); these make a multi-GPU trace readable -- does the
+    all-gather really sit under phase 1?  No-ops off the GPU."""
+    enabled = True
+
+    def __init__(self, name, on):
+        self.name, self.on = name, on and _Range.enabled
+
+    def __enter__(self):
+        if self.on:
+            try:
+                torch.cuda.nvtx.range_push(self.name)
+            except Exception:  # noqa: BLE001  (a torch build without the marker library)
+                self.on = _Range.enabled = False
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            torch.cuda.nvtx.range_pop()
+        return False
+
+
+# slots per block of a variant that pins one (block_of_variant, csrc/nbody_internal.h)
+BLOCK_OF_VARIANT = {11: 256, 12: 512, 14: 1024, 18: 2048, 21: 64, 22: 128, 24: 256, 28: 512}
+
+
+def slab_slots(bodies: int, variant) -> int:
+    """Slots of a slab holding `bodies`: slab_slots() of csrc/nbody_internal.h -- whole tiles and
+    whole blocks of the pair-symmetric kernels the library would choose or the variant pins."""
+    unit = 2048 if bodies >= 65536 else (1024 if bodies >= 8192 else TILE)
+    unit = max(unit, BLOCK_OF_VARIANT.get(variant, 0))
+    return round_up(bodies, unit)
 
 
 def shard_counts(n: int, world: int):
@@ -164,10 +200,7 @@ class ShardedNBody:
         # with their largest block
         big = max(self.counts)
         variant = getattr(self.backend, "variant", None)
-        unit = 2048 if (big >= 65536 or variant == VARIANT_SYM8) else (1024 if big >= 8192 else TILE)
-        if variant == VARIANT_SYMW8:
-            unit = max(unit, 512)
-        self.S = S = round_up(big, unit)
+        self.S = S = slab_slots(big, variant)
 
         dev = self.device
         if scene is None:
@@ -241,8 +274,15 @@ class ShardedNBody:
                 self.backend.slab_shift(self.pos[0][r], self.vel if r == self.rank else None, self.counts[r], S, shift)
         self.pos.append(self.pos[0].clone())
 
+    def _range(self, name):
+        return _Range(name, self.device.type == "cuda")
+
     # ------------------------------------------------------------------ one small step
     def step(self, snapshot=False):
+        with self._range("nbody small step"):
+            self._step(snapshot)
+
+    def _step(self, snapshot):
         snap = self.snap if snapshot else None
         if self.integrator != KDK:
             self._evaluate(snap, self.dt)       # forces at pos[cur]; the update writes pos[cur ^ 1]
@@ -272,19 +312,25 @@ class ShardedNBody:
             self.backend.step(acc_in=None, acc_out=None, snapshot=snap, ranges=((0, self.n), (0, 0)), **common, **extra)
         elif self.workspace is not None:
             self._sym_forces(cur, common)
-            self._reduce_scatter()
-            self._integrate(common, snap)
+            with self._range("reduce-scatter of partial sums"):
+                self._reduce_scatter()
+            with self._range("integrate"):
+                self._integrate(common, snap)
         elif not self.overlap or self._fresh:
             if not self._fresh:
                 self._all_gather(cur, async_op=False)
             self.backend.step(acc_in=None, acc_out=None, snapshot=snap, ranges=((0, P * S), (0, 0)), **common)
         else:
-            work = self._all_gather(cur, async_op=True)           # remote slabs, in flight
-            self.backend.step(acc_in=None, acc_out=self.acc, snapshot=None,
-                              ranges=((r * S, (r + 1) * S), (0, 0)), **common)   # own slab meanwhile
-            work.wait()                                           # stream-ordered, not a host block
-            self.backend.step(acc_in=self.acc, acc_out=None, snapshot=snap,
-                              ranges=((0, r * S), ((r + 1) * S, P * S)), **common)
+            with self._range("all-gather of positions (issue)"):
+                work = self._all_gather(cur, async_op=True)       # remote slabs, in flight
+            with self._range("phase 1: own slab"):
+                self.backend.step(acc_in=None, acc_out=self.acc, snapshot=None,
+                                  ranges=((r * S, (r + 1) * S), (0, 0)), **common)   # own slab meanwhile
+            with self._range("all-gather of positions (wait)"):
+                work.wait()                                       # stream-ordered, not a host block
+            with self._range("phase 2: remote slabs"):
+                self.backend.step(acc_in=self.acc, acc_out=None, snapshot=snap,
+                                  ranges=((0, r * S), ((r + 1) * S, P * S)), **common)
 
     # -- pair-symmetric step over several ranks, in its three parts (the one-GPU loop-back
     # test drives them separately): partial sums for EVERY slot -> reduce-scatter -> integrate
@@ -292,14 +338,20 @@ class ShardedNBody:
         kw = dict(acc_in=None, snapshot=None, ranges=((0, 0), (0, 0)), workspace=self.workspace,
                   variant=self.sym_variant, **common)
         if self.overlap and not self._fresh:
-            work = self._all_gather(cur, async_op=True)             # remote slabs, in flight
-            self.backend.step(acc_out=None, phase=1, **kw)          # diagonal tiles: own slab only
-            work.wait()
-            self.backend.step(acc_out=self.acc_all, phase=2, **kw)  # all other tiles, then gather
+            with self._range("all-gather of positions (issue)"):
+                work = self._all_gather(cur, async_op=True)             # remote slabs, in flight
+            with self._range("phase 1: diagonal tiles"):
+                self.backend.step(acc_out=None, phase=1, **kw)          # diagonal tiles: own slab only
+            with self._range("all-gather of positions (wait)"):
+                work.wait()
+            with self._range("phase 2: all other tiles"):
+                self.backend.step(acc_out=self.acc_all, phase=2, **kw)  # all other tiles, then gather
         else:
             if not self._fresh:
-                self._all_gather(cur, async_op=False)
-            self.backend.step(acc_out=self.acc_all, phase=0, **kw)
+                with self._range("all-gather of positions (blocking)"):
+                    self._all_gather(cur, async_op=False)
+            with self._range("phase 0: all tiles"):
+                self.backend.step(acc_out=self.acc_all, phase=0, **kw)
 
     def _reduce_scatter(self):
         import torch.distributed as dist
@@ -370,6 +422,47 @@ class ShardedNBody:
         if self.acc_all is not None:
             self._reduce_scatter()
         torch.cuda.synchronize(self.device)
+
+    def time_collectives(self, reps=5):
+        """Milliseconds of each collective of a small step on its own (mean of `reps` blocking
+        calls after one untimed call; the state is not changed, as in warm_collectives).  HIP
+        events on the launch stream, which waits for the collective's own stream; a gloo
+        rehearsal is staged through the host and is timed with the host's clock instead.
+        None when this object runs no collective."""
+        if not self.multi or self.device.type != "cuda":
+            return None
+        import time
+        import torch.distributed as dist
+        events = dist.get_backend(self.group) == "nccl"
+
+        def timed(call):
+            call()
+            torch.cuda.synchronize(self.device)
+            if events:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(reps):
+                    call()
+                e1.record()
+                torch.cuda.synchronize(self.device)
+                return e0.elapsed_time(e1) / reps
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                call()
+            torch.cuda.synchronize(self.device)
+            return (time.perf_counter() - t0) / reps * 1e3
+
+        out = {"all_gather": timed(lambda: self._all_gather(self.pos[self.cur], async_op=False)),
+               "reduce_scatter": timed(self._reduce_scatter) if self.acc_all is not None else None,
+               "timer": "hip_events_on_launch_stream" if events else "host_clock_host_staged",
+               "reps": reps, "all_gather_bytes_per_rank": 3 * self.S * 8,
+               "reduce_scatter_bytes_in_per_rank": 3 * self.S * 8 * self.world if self.acc_all is not None else 0}
+        return out
+
+    def all_masses(self):
+        """(n,) masses of every body, from the device's copy."""
+        m = self.mass.cpu().numpy()
+        return np.concatenate([m[r, :self.counts[r]] for r in range(self.world)])
 
     def sync_positions(self):
         """Make every slab of the current buffer current (needed before reading remote slabs)."""

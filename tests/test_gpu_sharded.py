@@ -435,3 +435,68 @@ def test_bench_self_launch_two_ranks_share_the_gpu():
     assert line["n_gpus"] == 2 and line["steps"] == 3 and line["scaling"] == "strong"
     assert line["config"]["bodies"] == 131072 and line["value"] > 0
     assert "cpu_baseline" not in line and "other_configs" not in line     # N = 1 only
+    # what makes a multi-rank line self-proving: the communicator's own view ...
+    c = line["collectives"]
+    assert c["world_size_seen"] == 2 and c["backend"] == "gloo" and not c["is_rccl"]
+    assert [d["rank"] for d in c["devices"]] == [0, 1] and len({d["pid"] for d in c["devices"]}) == 2
+    assert c["distinct_devices"] == 1, "--share-devices: both ranks on the one GPU, and the line says so"
+    assert "MI355X" in c["devices"][0]["name"] or "AMD" in c["devices"][0]["name"]
+    # ... every rank's own clock, the two collectives on their own ...
+    assert len(line["per_rank_ms_per_step"]) == 2 and all(t > 0 for t in line["per_rank_ms_per_step"])
+    assert max(line["per_rank_ms_per_step"]) == pytest.approx(line["ms_per_step"], rel=1e-3)
+    cm = line["collective_ms"]
+    assert cm["all_gather"] > 0 and cm["reduce_scatter"] > 0 and cm["all_gather_bytes_per_rank"] == 3 * 8 * 65536
+    # ... and the verification leg, on by default with more than one rank
+    v = line["verify"]
+    assert v["ok"] is True and v["steps_before"] == 4
+    assert v["rows_vs_oracle"]["ok"] and v["rows_vs_oracle"]["max_err_over_max_acc"] <= 1e-12
+    assert v["momentum"]["ok"] and v["positions_vs_one_gpu"]["ok"] and v["positions_vs_one_gpu"]["steps"] == 5
+    assert "RCCL" not in line["config"]["parallelism"] and "gloo" in line["config"]["parallelism"]
+
+
+def _bench(*flags, timeout=400):
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+    repo = Path(__file__).resolve().parent.parent
+    r = subprocess.run([sys.executable, str(repo / "bench.py"), *flags], capture_output=True, text=True, timeout=timeout)
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    return r, (json.loads(lines[0]) if len(lines) == 1 else None)
+
+
+def test_bench_one_rank_through_rccl_verifies_itself(tmp_path):
+    """`--gpus 1 --force-collectives --verify`: the multi-rank code path through REAL RCCL (a
+    communicator of one rank is all a one-GPU box allows) -- the line reports what the
+    communicator saw and the verification passes; a one-GPU run of the same command writes the
+    checksum file the RCCL run is then also compared with."""
+    common = ["--bodies", "65536", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"]
+    ck = tmp_path / "pos.npy"
+    r, one = _bench(*common, "--verify", "--write-checksum", str(ck))
+    assert r.returncode == 0 and one is not None, r.stderr[-2000:]
+    assert one["config"]["parallelism"] == "one GPU, no collective" and "collectives" not in one
+    assert one["verify"]["ok"] and one["verify"]["checksum_written"]["steps"] == 5 and ck.exists()
+    assert "positions_vs_one_gpu" not in one["verify"]
+    r, line = _bench(*common, "--force-collectives", "--verify", "--reference-checksum", str(ck))
+    assert r.returncode == 0 and line is not None, r.stderr[-2000:]
+    c = line["collectives"]
+    assert c["is_rccl"] and c["backend"] == "nccl" and c["world_size_seen"] == 1 and c["rccl_version"][0].isdigit()
+    assert line["collective_ms"]["timer"] == "hip_events_on_launch_stream"
+    assert line["collective_ms"]["all_gather"] > 0 and line["collective_ms"]["reduce_scatter"] > 0
+    v = line["verify"]
+    assert v["ok"] and v["rows_vs_oracle"]["ok"] and v["momentum"]["ok"]
+    assert v["positions_vs_one_gpu"]["ok"] and v["positions_vs_reference_file"]["ok"]
+    assert "RCCL" in line["config"]["parallelism"] and "--force-collectives rehearsal" in line["config"]["parallelism"]
+
+
+def test_bench_verification_failure_is_a_non_zero_exit(tmp_path):
+    """A reference file that does not match fails the run: non-zero exit, the line still printed
+    with verify.ok false (a wrong multi-rank result must not pass as a number)."""
+    import numpy as np
+    bad = tmp_path / "bad.npy"
+    np.save(bad, np.zeros((8192, 3)))
+    r, line = _bench("--bodies", "8192", "--steps", "2", "--warmup", "0", "--no-cpu-baseline", "--verify",
+                     "--reference-checksum", str(bad))
+    assert r.returncode != 0 and "verification FAILED" in r.stderr
+    assert line is not None and line["verify"]["ok"] is False
+    assert line["verify"]["rows_vs_oracle"]["ok"] and not line["verify"]["positions_vs_reference_file"]["ok"]
