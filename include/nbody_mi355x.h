@@ -274,14 +274,20 @@ int nbody_mi355x_create(const nbody_mi355x_config* cfg, nbody_mi355x_sim** sim);
  * "device list", 8e; the reference has one GPU, particle_simulation_GPU.cu:13-35).
  * devices[k] owns the k-th contiguous i-range of bodies -- the partition of the
  * reference's CPU threads, particle_simulation.h:98-110.  Per small step the
- * shards exchange new positions (and, on the pair-symmetric path, partial sums)
- * by peer copies ordered with events; the host does not block inside a big
- * step.  A device ordinal may appear more than once (several shards on one GPU:
- * how the path is rehearsed on a one-GPU machine).  cfg->device is ignored.
+ * shards exchange new positions (all-gather) and, on the pair-symmetric path,
+ * partial sums (reduce-scatter); the host does not block inside a big step.
+ * The exchanges are RCCL collectives over xGMI (one communicator over the listed
+ * devices, librccl resolved at run time) whenever every shard has a GPU of its own
+ * and the communicator passes a bit-exact self-check at create -- a patterned
+ * buffer all-gathered and reduce-scattered both by RCCL and by peer copies;
+ * otherwise, or with NBODY_MI355X_MULTI_RCCL=0 in the environment, they are peer
+ * copies ordered with events (nbody_mi355x_exchange_backend says which).
+ * A device ordinal may appear more than once (several shards on one GPU: how the
+ * path is rehearsed on a one-GPU machine; peer copies).  cfg->device is ignored.
  * Every other handle function works on the result unchanged.  On success
  * nbody_mi355x_last_error() is empty, or holds a note: direct peer access between two of
  * the devices could not be enabled (the runtime then stages those copies through the host),
- * or NBODY_MI355X_MULTI_RCCL=1 was set and RCCL could not be used (peer copies instead). */
+ * or RCCL could not be used and why (library missing, init failed, self-check failed). */
 int nbody_mi355x_create_multi(const nbody_mi355x_config* cfg, const int32_t* devices,
                               int32_t num_devices, nbody_mi355x_sim** sim);
 /* ref: FreeDeviceMemory, particle_simulation_GPU.cu:216-231. */
@@ -322,6 +328,19 @@ int nbody_mi355x_energy(nbody_mi355x_sim* sim, double* ke, double* pe);
 int nbody_mi355x_kernel_in_use(nbody_mi355x_sim* sim, int32_t* variant, int64_t* workspace_bytes);
 /* Device time (hipEvent) of the kernels of the last nbody_mi355x_run, seconds. */
 int nbody_mi355x_last_run_seconds(nbody_mi355x_sim* sim, double* seconds);
+/* Device time of the two exchanges of the LAST small step of the last completed run, seconds,
+ * the longest over the shards: *positions = the all-gather of the new positions (on the comm
+ * streams, under the next step's diagonal tiles), *partial_sums = the reduce-scatter of the
+ * pair-symmetric partial sums (on the compute streams: NOT overlapped, this is what it costs a
+ * step); 0 where the step had no such exchange and on a one-device handle.  The reference has
+ * one GPU and no exchange (particle_simulation_GPU.cu:145-178); it stands beside its per-big-step
+ * timer, particle_simulation.h:203-207. */
+int nbody_mi355x_last_exchange_seconds(nbody_mi355x_sim* sim, double* positions, double* partial_sums);
+/* How a multi-device handle exchanges: NONE (one device), PEER_COPIES or RCCL (see create_multi). */
+#define NBODY_MI355X_EXCHANGE_NONE 0
+#define NBODY_MI355X_EXCHANGE_PEER_COPIES 1
+#define NBODY_MI355X_EXCHANGE_RCCL 2
+int nbody_mi355x_exchange_backend(nbody_mi355x_sim* sim, int32_t* backend);
 
 /* --------------------------------------------------- initial conditions (host)
  * Synthetic scenes with an in-library portable RNG (splitmix64-seeded

@@ -65,10 +65,12 @@ __device__ __forceinline__ void pair_f32(double xi, double yi, double zi, double
   const float dx = static_cast<float>(xj - xi);
   const float dy = static_cast<float>(yj - yi);
   const float dz = static_cast<float>(zj - zi);
-  const float r2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, __builtin_fmaf(dx, dx, eps2)));
-  const float y0 = __builtin_amdgcn_rsqf(r2);
+  // (the select is on the BARE separation: the self pair has d2 == 0 whatever the softening, and
+  // its weight m eps2^-3/2 may be beyond float -- inf * 0 would be NaN)
+  const float d2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+  const float y0 = __builtin_amdgcn_rsqf(d2 + eps2);
   const float s3 = (mj * y0) * (y0 * y0);
-  const float s = (r2 > 0.0f) ? s3 : 0.0f;
+  const float s = (d2 > 0.0f) ? s3 : 0.0f;
   ax = __builtin_fmaf(s, dx, ax);
   ay = __builtin_fmaf(s, dy, ay);
   az = __builtin_fmaf(s, dz, az);

@@ -62,6 +62,8 @@ bool scene_valid(const nbody_mi355x_scene* scene, const char* who);  // nbody_sc
 int multi_enqueue(MultiSim* m, int64_t substeps, double* snapshot_out);
 int multi_wait(MultiSim* m, double* seconds);
 int multi_download(MultiSim* m, double* particles);
+int multi_exchange_seconds(MultiSim* m, double* positions, double* sums);
+bool multi_uses_rccl(const MultiSim* m);
 int multi_energy(MultiSim* m, double* ke, double* pe);
 int multi_kernel_in_use(MultiSim* m, int32_t* variant, int64_t* workspace_bytes);
 }  // namespace nbody_internal

@@ -17,13 +17,24 @@
 //   one-sided path (small systems, or no room for the workspace): A+B are one step call
 //   after the exchange.
 //
-// The two exchanges are peer copies ordered by events by default.  With
-// NBODY_MI355X_MULTI_RCCL=1 and all shards on distinct GPUs they are ncclReduceScatter and an
-// in-place ncclAllGather of one communicator over the listed devices (ncclCommInitAll), the
-// library resolved at run time from the process (torch's copy if one is mapped) or
-// /opt/rocm/lib -- no link-time dependency.  That path has only been run with a one-rank
-// communicator (a one-GPU box cannot do more): it is opt-in until it has run on a multi-GPU
-// node, and its sums are added in RCCL's order, not shard order.
+// The two exchanges are RCCL collectives -- ncclReduceScatter of the partial sums and an
+// in-place ncclAllGather of the new positions, one communicator over the listed devices
+// (ncclCommInitAll) -- whenever every shard sits on a GPU of its own and librccl can be
+// resolved at run time (from the process: torch's copy if one is mapped; else /opt/rocm/lib:
+// no link-time dependency) AND the communicator passes a self-check at create: a small
+// patterned buffer is all-gathered and reduce-scattered both ways, by RCCL and by the
+// event-ordered peer copies, and the results must agree bit for bit (rccl_self_check).  Where
+// any of that fails -- or NBODY_MI355X_MULTI_RCCL=0 -- the exchanges are the peer copies, and
+// nbody_mi355x_last_error() says why after the (successful) create.  NBODY_MI355X_MULTI_RCCL=1
+// asks for the communicator also where the default would not build one (a single shard).
+// RCCL adds the partial sums in ITS order (a ring's), the peer copies in shard order: each is
+// bit-reproducible run to run, the two agree to rounding.
+//
+// Why the collectives alone order the shards (no waits on peers' events in that mode): a
+// collective reads and writes rank q's buffers only inside q's own collective kernel, which
+// sits in q's stream behind q's waits -- a sender pushes into a peer's user buffer only after
+// that peer's kernel has posted it.  So the hazards the peer copies close with events
+// (gather_positions, multi_step) are closed by stream order on each side.
 //
 // Ordering argument: see multi_step and gather_positions.  A device ordinal may appear more
 // than once: several shards on one GPU, which is how this path is tested on a one-GPU machine
@@ -33,6 +44,7 @@
 
 #include <algorithm>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -61,6 +73,8 @@ struct Shard {
   hipStream_t stream = nullptr;  // compute
   hipStream_t comm = nullptr;    // the exchange of positions
   hipEvent_t ev_partials = nullptr, ev_pos = nullptr, ev_gathered = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
+  // around the two exchanges of the latest small step (timing on): positions on comm, sums on stream
+  hipEvent_t ev_x0 = nullptr, ev_x1 = nullptr, ev_r0 = nullptr, ev_r1 = nullptr;
   void* nccl = nullptr;          // ncclComm_t of this shard (RCCL path only)
 };
 
@@ -77,6 +91,42 @@ struct Rccl {
 };
 constexpr int kNcclDouble = 8, kNcclSum = 0;  // rccl.h: ncclFloat64 = 8, ncclSum = 0
 
+// Named ranges for a rocprofv3 --marker-trace of a multi-GPU run (the reference's only
+// timing hooks are wall-clock timers around a big step, particle_simulation.h:203-207): big
+// step, phase 1, exchange, phase 2, reduce-scatter.  roctx is resolved at run time like RCCL
+// -- the profiler's copy if it is mapped, else the tracer library torch links, else
+// /opt/rocm/lib; without any of them the ranges are no-ops -- no link-time dependency.
+struct Roctx {
+  int (*push)(const char*) = nullptr;
+  int (*pop)() = nullptr;
+  Roctx() {
+    const char* off = getenv("NBODY_MI355X_ROCTX");
+    if (off && atoi(off) == 0) return;
+    void* lib = nullptr;
+    for (const char* name : {"librocprofiler-sdk-roctx.so.1", "libroctx64.so.4", "libroctx64.so"})
+      if (!lib) lib = dlopen(name, RTLD_NOW | RTLD_NOLOAD);
+    for (const char* name : {"librocprofiler-sdk-roctx.so.1", "/opt/rocm/lib/librocprofiler-sdk-roctx.so.1", "libroctx64.so.4"})
+      if (!lib) lib = dlopen(name, RTLD_NOW);
+    if (!lib) return;
+    push = reinterpret_cast<int (*)(const char*)>(dlsym(lib, "roctxRangePushA"));
+    pop = reinterpret_cast<int (*)()>(dlsym(lib, "roctxRangePop"));
+    if (!push || !pop) push = nullptr, pop = nullptr;
+  }
+};
+inline const Roctx& roctx() {
+  static const Roctx r;
+  return r;
+}
+struct RangeScope {  // host-side range: what is ENQUEUED inside it (the kernels carry their own names)
+  bool on;
+  explicit RangeScope(const char* name) : on(roctx().push != nullptr) {
+    if (on) roctx().push(name);
+  }
+  ~RangeScope() {
+    if (on) roctx().pop();
+  }
+};
+
 struct MultiSim {
   nbody_mi355x_config cfg{};
   int64_t n = 0, S = 0;
@@ -84,7 +134,9 @@ struct MultiSim {
   int cur = 0;
   bool sym = false;
   bool kacc_valid = false;  // KDK: kacc holds the sums at the current positions
-  bool rccl = false;        // the exchanges are RCCL collectives (opt-in), else peer copies
+  bool rccl = false;        // the exchanges are RCCL collectives (self-checked at create), else peer copies
+  bool sums_timed = false;  // the latest small step exchanged partial sums (ev_r0 / ev_r1 are set)
+  bool pos_timed = false;   // ... and positions (ev_x0 / ev_x1)
   Rccl nccl;
   int sym_variant = NBODY_MI355X_VARIANT_SYM;
   std::vector<Shard> sh;
@@ -160,7 +212,7 @@ void free_shard(Shard& s) {
   }
   if (s.workspace) (void)hipFree(s.workspace);
   s.workspace = nullptr;
-  for (hipEvent_t* e : {&s.ev_partials, &s.ev_pos, &s.ev_gathered, &s.ev_t0, &s.ev_t1}) {
+  for (hipEvent_t* e : {&s.ev_partials, &s.ev_pos, &s.ev_gathered, &s.ev_t0, &s.ev_t1, &s.ev_x0, &s.ev_x1, &s.ev_r0, &s.ev_r1}) {
     if (*e) (void)hipEventDestroy(*e);
     *e = nullptr;
   }
@@ -200,18 +252,23 @@ int gather_positions(MultiSim& m, int buf) {
   const int P = m.P;
   const int64_t slab = 3 * m.S;
   const size_t slab_bytes = sizeof(double) * static_cast<size_t>(slab);
+  RangeScope range("nbody exchange: positions (all-gather)");
   for (int q = 0; q < P; q++) {
     Shard& s = m.sh[q];
     M_TRY(hipSetDevice(s.device), NBODY_MI355X_ERR_NO_DEVICE, "hipSetDevice");
     M_TRY(hipStreamWaitEvent(s.comm, s.ev_pos, 0), NBODY_MI355X_ERR_LAUNCH, "wait own positions");
+    if (!m.rccl)
+      for (int r = 0; r < P; r++)
+        if (r != q) M_TRY(hipStreamWaitEvent(s.comm, m.sh[r].ev_pos, 0), NBODY_MI355X_ERR_LAUNCH, "wait positions");
+    M_TRY(hipEventRecord(s.ev_x0, s.comm), NBODY_MI355X_ERR_LAUNCH, "event record");
     if (m.rccl) continue;
     for (int r = 0; r < P; r++) {
       if (r == q) continue;
-      M_TRY(hipStreamWaitEvent(s.comm, m.sh[r].ev_pos, 0), NBODY_MI355X_ERR_LAUNCH, "wait positions");
       M_TRY(pull(s, s.comm, s.pos[buf] + r * slab, m.sh[r], m.sh[r].pos[buf] + r * slab, slab_bytes),
             NBODY_MI355X_ERR_LAUNCH, "pull positions");
     }
     M_TRY(hipEventRecord(s.ev_gathered, s.comm), NBODY_MI355X_ERR_LAUNCH, "event record");
+    M_TRY(hipEventRecord(s.ev_x1, s.comm), NBODY_MI355X_ERR_LAUNCH, "event record");
   }
   if (m.rccl) {  // one in-place all-gather: every shard's own slab into its place everywhere
     NCCL_TRY(m, m.nccl.GroupStart(), "ncclGroupStart");
@@ -225,8 +282,10 @@ int gather_positions(MultiSim& m, int buf) {
       Shard& s = m.sh[q];
       M_TRY(hipSetDevice(s.device), NBODY_MI355X_ERR_NO_DEVICE, "hipSetDevice");
       M_TRY(hipEventRecord(s.ev_gathered, s.comm), NBODY_MI355X_ERR_LAUNCH, "event record");
+      M_TRY(hipEventRecord(s.ev_x1, s.comm), NBODY_MI355X_ERR_LAUNCH, "event record");
     }
   }
+  m.pos_timed = true;
   return NBODY_MI355X_OK;
 }
 
@@ -238,80 +297,107 @@ int multi_step(MultiSim& m, bool snapshot, int integrator, double dt) {
   const int64_t S = m.S, slab = 3 * S;
   const size_t slab_bytes = sizeof(double) * static_cast<size_t>(slab);
   const int nxt = m.cur ^ 1;
+  m.sums_timed = m.pos_timed = false;
   if (m.sym) {
     // A1: the diagonal tiles need the own slab only, which the shard wrote itself: they run
     //     while the comm stream is still fetching the other slabs of pos[cur].  (Their sums
     //     stay in the workspace; the workspace's previous contents were consumed by the
     //     gather kernel of the last step's A2, earlier on this stream.)
-    for (int r = 0; r < P; r++) {
-      Shard& s = m.sh[r];
-      M_TRY(hipSetDevice(s.device), NBODY_MI355X_ERR_NO_DEVICE, "hipSetDevice");
-      nbody_mi355x_step_args a = base_args(m, s, r);
-      a.variant = m.sym_variant;
-      a.workspace = s.workspace;
-      a.workspace_bytes = s.workspace_bytes;
-      a.phase = 1;
-      const int rc = nbody_mi355x_step_f64(&a, s.stream);
-      if (rc != NBODY_MI355X_OK) return rc;
+    {
+      RangeScope range("nbody phase 1: diagonal tiles (own slab, under the exchange)");
+      for (int r = 0; r < P; r++) {
+        Shard& s = m.sh[r];
+        M_TRY(hipSetDevice(s.device), NBODY_MI355X_ERR_NO_DEVICE, "hipSetDevice");
+        nbody_mi355x_step_args a = base_args(m, s, r);
+        a.variant = m.sym_variant;
+        a.workspace = s.workspace;
+        a.workspace_bytes = s.workspace_bytes;
+        a.phase = 1;
+        const int rc = nbody_mi355x_step_f64(&a, s.stream);
+        if (rc != NBODY_MI355X_OK) return rc;
+      }
     }
     // A2: everything else, once the exchange is complete.  acc_all of shard r was last read by
     //     its peers in B of the previous step; r's wait on ev_gathered is a wait on every
     //     peer's ev_pos of that step, recorded after those reads.
-    for (int r = 0; r < P; r++) {
-      Shard& s = m.sh[r];
-      M_TRY(hipSetDevice(s.device), NBODY_MI355X_ERR_NO_DEVICE, "hipSetDevice");
-      M_TRY(hipStreamWaitEvent(s.stream, s.ev_gathered, 0), NBODY_MI355X_ERR_LAUNCH, "wait exchange");
-      nbody_mi355x_step_args a = base_args(m, s, r);
-      a.acc_out = s.acc_all;
-      a.variant = m.sym_variant;
-      a.workspace = s.workspace;
-      a.workspace_bytes = s.workspace_bytes;
-      a.phase = 2;
-      const int rc = nbody_mi355x_step_f64(&a, s.stream);
-      if (rc != NBODY_MI355X_OK) return rc;
-      M_TRY(hipEventRecord(s.ev_partials, s.stream), NBODY_MI355X_ERR_LAUNCH, "event record");
+    {
+      RangeScope range("nbody phase 2: all other tiles");
+      for (int r = 0; r < P; r++) {
+        Shard& s = m.sh[r];
+        M_TRY(hipSetDevice(s.device), NBODY_MI355X_ERR_NO_DEVICE, "hipSetDevice");
+        M_TRY(hipStreamWaitEvent(s.stream, s.ev_gathered, 0), NBODY_MI355X_ERR_LAUNCH, "wait exchange");
+        nbody_mi355x_step_args a = base_args(m, s, r);
+        a.acc_out = s.acc_all;
+        a.variant = m.sym_variant;
+        a.workspace = s.workspace;
+        a.workspace_bytes = s.workspace_bytes;
+        a.phase = 2;
+        const int rc = nbody_mi355x_step_f64(&a, s.stream);
+        if (rc != NBODY_MI355X_OK) return rc;
+        M_TRY(hipEventRecord(s.ev_partials, s.stream), NBODY_MI355X_ERR_LAUNCH, "event record");
+      }
     }
     // B: "reduce-scatter", then integrate.  r's slab of pos[next] was last read by its peers
     //    in C two steps ago; each peer recorded ev_partials (waited on here) after its wait on
-    //    the ev_gathered that closed that read.
-    if (m.rccl) {
-      NCCL_TRY(m, m.nccl.GroupStart(), "ncclGroupStart");
+    //    the ev_gathered that closed that read.  (RCCL: see the file header.)
+    {
+      RangeScope range("nbody exchange: partial sums (reduce-scatter)");
       for (int r = 0; r < P; r++) {
         Shard& s = m.sh[r];
-        NCCL_TRY(m, m.nccl.ReduceScatter(s.acc_all, s.acc, static_cast<size_t>(slab), kNcclDouble, kNcclSum, s.nccl, s.stream),
-                 "ncclReduceScatter");
+        M_TRY(hipSetDevice(s.device), NBODY_MI355X_ERR_NO_DEVICE, "hipSetDevice");
+        if (!m.rccl)
+          for (int q = 0; q < P; q++)
+            if (q != r) M_TRY(hipStreamWaitEvent(s.stream, m.sh[q].ev_partials, 0), NBODY_MI355X_ERR_LAUNCH, "wait partials");
+        M_TRY(hipEventRecord(s.ev_r0, s.stream), NBODY_MI355X_ERR_LAUNCH, "event record");
       }
-      NCCL_TRY(m, m.nccl.GroupEnd(), "ncclGroupEnd");
-    }
-    for (int r = 0; r < P; r++) {
-      Shard& s = m.sh[r];
-      M_TRY(hipSetDevice(s.device), NBODY_MI355X_ERR_NO_DEVICE, "hipSetDevice");
-      if (!m.rccl) {
-        for (int q = 0; q < P; q++) {
-          if (q == r) continue;
-          M_TRY(hipStreamWaitEvent(s.stream, m.sh[q].ev_partials, 0), NBODY_MI355X_ERR_LAUNCH, "wait partials");
-          M_TRY(pull(s, s.stream, s.stage + q * slab, m.sh[q], m.sh[q].acc_all + r * slab, slab_bytes),
-                NBODY_MI355X_ERR_LAUNCH, "pull partial sums");
+      if (m.rccl) {
+        NCCL_TRY(m, m.nccl.GroupStart(), "ncclGroupStart");
+        for (int r = 0; r < P; r++) {
+          Shard& s = m.sh[r];
+          NCCL_TRY(m, m.nccl.ReduceScatter(s.acc_all, s.acc, static_cast<size_t>(slab), kNcclDouble, kNcclSum, s.nccl, s.stream),
+                   "ncclReduceScatter");
         }
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3(static_cast<unsigned>((slab + 255) / 256)), dim3(256), 0,
-                           s.stream, s.acc_all + r * slab, s.stage, P, r, slab, s.acc);
-        M_TRY(hipGetLastError(), NBODY_MI355X_ERR_LAUNCH, "reduce launch");
+        NCCL_TRY(m, m.nccl.GroupEnd(), "ncclGroupEnd");
       }
-      nbody_mi355x_step_args a = base_args(m, s, r);
-      a.integrator = integrator;
-      a.dt = dt;
-      a.acc_in = s.acc;  // no j range: acc_in -> the integrator's update (+ snapshot)
-      a.variant = 1;
-      a.snapshot = snapshot ? s.snap : nullptr;
-      const int rc = nbody_mi355x_step_f64(&a, s.stream);
-      if (rc != NBODY_MI355X_OK) return rc;
-      M_TRY(hipEventRecord(s.ev_pos, s.stream), NBODY_MI355X_ERR_LAUNCH, "event record");
+      for (int r = 0; r < P; r++) {
+        Shard& s = m.sh[r];
+        M_TRY(hipSetDevice(s.device), NBODY_MI355X_ERR_NO_DEVICE, "hipSetDevice");
+        if (!m.rccl) {
+          for (int q = 0; q < P; q++) {
+            if (q == r) continue;
+            M_TRY(pull(s, s.stream, s.stage + q * slab, m.sh[q], m.sh[q].acc_all + r * slab, slab_bytes),
+                  NBODY_MI355X_ERR_LAUNCH, "pull partial sums");
+          }
+          hipLaunchKernelGGL(reduce_partials_kernel, dim3(static_cast<unsigned>((slab + 255) / 256)), dim3(256), 0,
+                             s.stream, s.acc_all + r * slab, s.stage, P, r, slab, s.acc);
+          M_TRY(hipGetLastError(), NBODY_MI355X_ERR_LAUNCH, "reduce launch");
+        }
+        M_TRY(hipEventRecord(s.ev_r1, s.stream), NBODY_MI355X_ERR_LAUNCH, "event record");
+      }
+      m.sums_timed = true;
+    }
+    {
+      RangeScope range("nbody integrate");
+      for (int r = 0; r < P; r++) {
+        Shard& s = m.sh[r];
+        M_TRY(hipSetDevice(s.device), NBODY_MI355X_ERR_NO_DEVICE, "hipSetDevice");
+        nbody_mi355x_step_args a = base_args(m, s, r);
+        a.integrator = integrator;
+        a.dt = dt;
+        a.acc_in = s.acc;  // no j range: acc_in -> the integrator's update (+ snapshot)
+        a.variant = 1;
+        a.snapshot = snapshot ? s.snap : nullptr;
+        const int rc = nbody_mi355x_step_f64(&a, s.stream);
+        if (rc != NBODY_MI355X_OK) return rc;
+        M_TRY(hipEventRecord(s.ev_pos, s.stream), NBODY_MI355X_ERR_LAUNCH, "event record");
+      }
     }
   } else {
     // one-sided: every shard sums over all slabs and integrates in one call, after the
     // exchange.  r's slab of pos[next] was last read by its peers in C two steps ago; r's wait
     // on ev_gathered of the step in between was a wait on ev_pos events its peers recorded
     // after their own waits on the ev_gathered that closed that read.
+    RangeScope range("nbody one-sided step (after the exchange)");
     for (int r = 0; r < P; r++) {
       Shard& s = m.sh[r];
       M_TRY(hipSetDevice(s.device), NBODY_MI355X_ERR_NO_DEVICE, "hipSetDevice");
@@ -343,6 +429,119 @@ int sync_all(MultiSim& m, int code, const char* what) {
     M_TRY(hipStreamSynchronize(s.comm), code, what);
   }
   return NBODY_MI355X_OK;
+}
+
+// The communicator's self-check at create (see the file header): both exchanges on a small
+// patterned buffer, by RCCL and by the event-ordered peer copies, must agree BIT FOR BIT.
+// The pattern is small integers, whose sums are exact in any order, so the two reduce-scatters
+// must give the same bits although they add in different orders.  Uses pos[0] / acc_all /
+// stage / acc of the shards as scratch (before any upload); returns false with the reason in
+// `why` when anything disagrees or fails.  Each shard's streams are idle on return.
+bool rccl_self_check(MultiSim& m, char* why, size_t why_len) {
+  const int P = m.P;
+  const int64_t len = 384;  // doubles per rank: 3 KiB -- all-gather P * len, reduce-scatter P * len in, len out
+  if (3 * m.S < len) { snprintf(why, why_len, "slab too small for the self-check"); return false; }
+  std::vector<double> host(static_cast<size_t>(P) * len), got_rccl, got_peer;
+  auto fail = [&](const char* what, hipError_t e) {
+    (void)hipGetLastError();
+    snprintf(why, why_len, "self-check: %s: %s", what, hipGetErrorString(e));
+    return false;
+  };
+  // scratch: a = pos[0] (P * len: gather target / reduce input), b = pos[1] (second target), c = vel (len: reduce output)
+  for (int r = 0; r < P; r++) {
+    Shard& s = m.sh[r];
+    hipError_t e = hipSetDevice(s.device);
+    if (e != hipSuccess) return fail("hipSetDevice", e);
+    // rank r's contribution for slot (q, i): an integer below 2^20 that differs by rank, slot and index
+    for (int q = 0; q < P; q++)
+      for (int64_t i = 0; i < len; i++) host[static_cast<size_t>(q) * len + i] = static_cast<double>((r + 1) * 4099 + q * 131 + i * 7 + ((i * (r + 3)) % 5));
+    e = hipMemcpyAsync(s.pos[0], host.data(), sizeof(double) * host.size(), hipMemcpyHostToDevice, s.stream);
+    if (e == hipSuccess) e = hipMemsetAsync(s.pos[1], 0xff, sizeof(double) * host.size(), s.stream);
+    if (e == hipSuccess) e = hipMemsetAsync(s.vel, 0xff, sizeof(double) * len, s.stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(s.stream);
+    if (e != hipSuccess) return fail("fill", e);
+  }
+  auto read_back = [&](std::vector<double>* out, bool gather) -> bool {
+    out->assign(static_cast<size_t>(P) * (gather ? P * len : len), 0.0);
+    for (int r = 0; r < P; r++) {
+      Shard& s = m.sh[r];
+      hipError_t e = hipSetDevice(s.device);
+      if (e == hipSuccess) e = hipStreamSynchronize(s.stream);
+      const size_t n = static_cast<size_t>(gather ? P * len : len);
+      if (e == hipSuccess) e = hipMemcpy(out->data() + r * n, gather ? s.pos[1] : s.vel, sizeof(double) * n, hipMemcpyDeviceToHost);
+      if (e != hipSuccess) { fail("read back", e); return false; }
+    }
+    return true;
+  };
+  // ---- all-gather of each rank's own block (block r of its pos[0]) into pos[1], both ways
+  for (int pass = 0; pass < 2; pass++) {
+    const bool rccl = pass == 0;
+    if (rccl) {
+      if (m.nccl.GroupStart() != 0) { snprintf(why, why_len, "self-check: ncclGroupStart failed"); return false; }
+      for (int r = 0; r < P; r++) {
+        Shard& s = m.sh[r];
+        const int rc = m.nccl.AllGather(s.pos[0] + r * len, s.pos[1], static_cast<size_t>(len), kNcclDouble, s.nccl, s.stream);
+        if (rc != 0) { (void)m.nccl.GroupEnd(); snprintf(why, why_len, "self-check: ncclAllGather: %s", m.nccl.GetErrorString ? m.nccl.GetErrorString(rc) : "error"); return false; }
+      }
+      if (m.nccl.GroupEnd() != 0) { snprintf(why, why_len, "self-check: ncclGroupEnd failed"); return false; }
+    } else {
+      for (int q = 0; q < P; q++) {
+        Shard& s = m.sh[q];
+        hipError_t e = hipSetDevice(s.device);
+        if (e == hipSuccess) e = hipMemsetAsync(s.pos[1], 0xff, sizeof(double) * static_cast<size_t>(P) * len, s.stream);
+        for (int r = 0; r < P && e == hipSuccess; r++)
+          e = pull(s, s.stream, s.pos[1] + r * len, m.sh[r], m.sh[r].pos[0] + r * len, sizeof(double) * len);
+        if (e != hipSuccess) return fail("peer all-gather", e);
+      }
+    }
+    if (!read_back(rccl ? &got_rccl : &got_peer, true)) return false;
+  }
+  if (got_rccl.size() != got_peer.size() || memcmp(got_rccl.data(), got_peer.data(), sizeof(double) * got_rccl.size()) != 0) {
+    snprintf(why, why_len, "self-check: ncclAllGather and the peer copies disagree");
+    return false;
+  }
+  // ---- reduce-scatter of pos[0] ([P][len] per rank) into vel, both ways
+  for (int pass = 0; pass < 2; pass++) {
+    const bool rccl = pass == 0;
+    if (rccl) {
+      if (m.nccl.GroupStart() != 0) { snprintf(why, why_len, "self-check: ncclGroupStart failed"); return false; }
+      for (int r = 0; r < P; r++) {
+        Shard& s = m.sh[r];
+        const int rc = m.nccl.ReduceScatter(s.pos[0], s.vel, static_cast<size_t>(len), kNcclDouble, kNcclSum, s.nccl, s.stream);
+        if (rc != 0) { (void)m.nccl.GroupEnd(); snprintf(why, why_len, "self-check: ncclReduceScatter: %s", m.nccl.GetErrorString ? m.nccl.GetErrorString(rc) : "error"); return false; }
+      }
+      if (m.nccl.GroupEnd() != 0) { snprintf(why, why_len, "self-check: ncclGroupEnd failed"); return false; }
+    } else {
+      for (int r = 0; r < P; r++) {
+        Shard& s = m.sh[r];
+        hipError_t e = hipSetDevice(s.device);
+        // stage in pos[1]: [P][len], block q = rank q's contribution for rank r
+        for (int q = 0; q < P && e == hipSuccess; q++)
+          if (q != r) e = pull(s, s.stream, s.pos[1] + q * len, m.sh[q], m.sh[q].pos[0] + r * len, sizeof(double) * len);
+        if (e != hipSuccess) return fail("peer reduce-scatter", e);
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3(static_cast<unsigned>((len + 255) / 256)), dim3(256), 0, s.stream,
+                           s.pos[0] + r * len, s.pos[1], P, r, len, s.vel);
+        e = hipGetLastError();
+        if (e != hipSuccess) return fail("reduce launch", e);
+      }
+    }
+    if (!read_back(rccl ? &got_rccl : &got_peer, false)) return false;
+  }
+  if (memcmp(got_rccl.data(), got_peer.data(), sizeof(double) * got_rccl.size()) != 0) {
+    snprintf(why, why_len, "self-check: ncclReduceScatter and the peer copies disagree");
+    return false;
+  }
+  // and against the closed form (both could be wrong together): sum over ranks of the pattern
+  for (int r = 0; r < P; r++)
+    for (int64_t i = 0; i < len; i++) {
+      double want = 0.0;
+      for (int q = 0; q < P; q++) want += static_cast<double>((q + 1) * 4099 + r * 131 + i * 7 + ((i * (q + 3)) % 5));
+      if (got_rccl[static_cast<size_t>(r) * len + i] != want) {
+        snprintf(why, why_len, "self-check: reduce-scatter sums are wrong (rank %d, element %lld)", r, (long long)i);
+        return false;
+      }
+    }
+  return true;
 }
 
 }  // namespace
@@ -451,7 +650,9 @@ int multi_create(const nbody_mi355x_config& cfg, const int32_t* devices, int32_t
          hipEventCreateWithFlags(&s.ev_partials, hipEventDisableTiming) == hipSuccess &&
          hipEventCreateWithFlags(&s.ev_pos, hipEventDisableTiming) == hipSuccess &&
          hipEventCreateWithFlags(&s.ev_gathered, hipEventDisableTiming) == hipSuccess &&
-         hipEventCreate(&s.ev_t0) == hipSuccess && hipEventCreate(&s.ev_t1) == hipSuccess;
+         hipEventCreate(&s.ev_t0) == hipSuccess && hipEventCreate(&s.ev_t1) == hipSuccess &&
+         hipEventCreate(&s.ev_x0) == hipSuccess && hipEventCreate(&s.ev_x1) == hipSuccess &&
+         hipEventCreate(&s.ev_r0) == hipSuccess && hipEventCreate(&s.ev_r1) == hipSuccess;
   }
   if (!ok) {
     (void)hipGetLastError();
@@ -487,10 +688,12 @@ int multi_create(const nbody_mi355x_config& cfg, const int32_t* devices, int32_t
       t.workspace_bytes = 0;
     }
   }
-  // RCCL for the two exchanges: opt-in (see the file header), one communicator over the
-  // listed devices; anything missing -> peer copies, and the reason is left in last_error
+  // RCCL for the two exchanges (see the file header): by default whenever every shard has a GPU
+  // of its own (and there is something to exchange), behind the self-check; anything missing
+  // -> the peer copies, and the reason is left in last_error
   const char* want = getenv("NBODY_MI355X_MULTI_RCCL");
-  if (want && atoi(want) != 0) {
+  const int mode = want ? (atoi(want) != 0 ? 1 : 0) : -1;  // 1 asked for, 0 refused, -1 default
+  if (mode == 1 || (mode == -1 && distinct && num > 1)) {
     if (!distinct) {
       set_error("create_multi: NBODY_MI355X_MULTI_RCCL needs every shard on its own GPU; using peer copies");
     } else if (!load_rccl(&m->nccl)) {
@@ -504,7 +707,18 @@ int multi_create(const nbody_mi355x_config& cfg, const int32_t* devices, int32_t
                   m->nccl.GetErrorString ? m->nccl.GetErrorString(rc) : "error");
       } else {
         for (int r = 0; r < num; r++) m->sh[r].nccl = comms[r];
-        m->rccl = true;
+        char why[200] = "";
+        if (rccl_self_check(*m, why, sizeof why)) {
+          m->rccl = true;
+        } else {
+          for (int r = 0; r < num; r++) {
+            (void)hipSetDevice(m->sh[r].device);
+            (void)hipStreamSynchronize(m->sh[r].stream);
+            (void)m->nccl.CommDestroy(m->sh[r].nccl);
+            m->sh[r].nccl = nullptr;
+          }
+          set_error("create_multi: RCCL %s; using peer copies", why);
+        }
       }
     }
   }
@@ -613,6 +827,7 @@ int multi_generate(MultiSim* m, const nbody_mi355x_scene& sc) {
 
 // Enqueues a big step on every shard's stream and returns; multi_wait completes it.
 int multi_enqueue(MultiSim* m, int64_t substeps, double* snapshot_out) {
+  RangeScope range("nbody big step (enqueue)");
   for (Shard& s : m->sh) {
     M_TRY(hipSetDevice(s.device), NBODY_MI355X_ERR_NO_DEVICE, "hipSetDevice");
     M_TRY(hipEventRecord(s.ev_t0, s.stream), NBODY_MI355X_ERR_LAUNCH, "event record");
@@ -621,6 +836,8 @@ int multi_enqueue(MultiSim* m, int64_t substeps, double* snapshot_out) {
   if (m->cfg.integrator == NBODY_MI355X_KDK) {
     // kick-drift-kick (see nbody_mi355x_run_async): sums carried in kacc (primed by a KDK step
     // with dt = 0); drift + exchange; substeps-1 fused steps; the closing kick with the snapshot
+    // (any error from here on leaves the shards half-kicked or half-drifted and kacc stale:
+    // kacc_valid goes false on every error return; the state then needs upload / generate)
     if (!m->kacc_valid) {
       const int rc = multi_step(*m, false, NBODY_MI355X_KDK, 0.0);
       if (rc != NBODY_MI355X_OK) return rc;
@@ -629,17 +846,29 @@ int multi_enqueue(MultiSim* m, int64_t substeps, double* snapshot_out) {
     const int nxt = m->cur ^ 1;
     for (int r = 0; r < m->P; r++) {
       Shard& s = m->sh[r];
-      M_TRY(hipSetDevice(s.device), NBODY_MI355X_ERR_NO_DEVICE, "hipSetDevice");
+      hipError_t e = hipSetDevice(s.device);
+      if (e != hipSuccess) {
+        (void)hipGetLastError();
+        m->kacc_valid = false;
+        set_error("multi: hipSetDevice: %s", hipGetErrorString(e));
+        return NBODY_MI355X_ERR_NO_DEVICE;
+      }
       // r's slab of pos[nxt] was last read by its peers two exchanges ago; since then r has
       // waited on an event each of them recorded after that read (ev_partials in B, or ev_pos
       // in the exchange in between)
       nbody_mi355x_step_args a = base_args(*m, s, r);
       const int rc = nbody_mi355x_kdk_drift_f64(&a, s.stream);
-      if (rc != NBODY_MI355X_OK) return rc;
-      M_TRY(hipEventRecord(s.ev_pos, s.stream), NBODY_MI355X_ERR_LAUNCH, "event record");
+      if (rc != NBODY_MI355X_OK) { m->kacc_valid = false; return rc; }
+      e = hipEventRecord(s.ev_pos, s.stream);
+      if (e != hipSuccess) {
+        (void)hipGetLastError();
+        m->kacc_valid = false;
+        set_error("multi: event record: %s", hipGetErrorString(e));
+        return NBODY_MI355X_ERR_LAUNCH;
+      }
     }
     const int prc = gather_positions(*m, nxt);
-    if (prc != NBODY_MI355X_OK) return prc;
+    if (prc != NBODY_MI355X_OK) { m->kacc_valid = false; return prc; }
     m->cur = nxt;
     for (int64_t k = 0; k + 1 < substeps; k++) {
       const int rc = multi_step(*m, false, NBODY_MI355X_KDK_CONTINUE, dt);
@@ -678,6 +907,23 @@ int multi_wait(MultiSim* m, double* seconds) {
   *seconds = longest;
   return NBODY_MI355X_OK;
 }
+
+// Device time of the two exchanges of the LAST small step of the last completed run, the
+// longest over the shards: positions (comm stream: from "every producer's slab is ready" to
+// "gathered") and partial sums (compute stream: pulls + reduction, or the reduce-scatter).
+int multi_exchange_seconds(MultiSim* m, double* positions, double* sums) {
+  *positions = *sums = 0.0;
+  for (Shard& s : m->sh) {
+    float ms = 0.f;
+    if (hipSetDevice(s.device) != hipSuccess) continue;
+    if (m->pos_timed && hipEventElapsedTime(&ms, s.ev_x0, s.ev_x1) == hipSuccess) *positions = std::max(*positions, ms * 1e-3);
+    if (m->sums_timed && hipEventElapsedTime(&ms, s.ev_r0, s.ev_r1) == hipSuccess) *sums = std::max(*sums, ms * 1e-3);
+  }
+  (void)hipGetLastError();
+  return NBODY_MI355X_OK;
+}
+
+bool multi_uses_rccl(const MultiSim* m) { return m->rccl; }
 
 int multi_download(MultiSim* m, double* particles) {
   const int64_t slab = 3 * m->S;

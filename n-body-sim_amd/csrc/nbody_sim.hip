@@ -547,6 +547,21 @@ extern "C" int nbody_mi355x_energy(nbody_mi355x_sim* s, double* ke, double* pe) 
   return NBODY_MI355X_OK;
 }
 
+extern "C" int nbody_mi355x_last_exchange_seconds(nbody_mi355x_sim* s, double* positions, double* partial_sums) {
+  if (!s || !positions || !partial_sums) { set_error("last_exchange_seconds: null argument"); return NBODY_MI355X_ERR_INVALID; }
+  *positions = *partial_sums = 0.0;
+  if (s->pending) { set_error("last_exchange_seconds: a run_async is pending: wait first"); return NBODY_MI355X_ERR_INVALID; }
+  if (!s->multi) return NBODY_MI355X_OK;  // one device: nothing is exchanged
+  return nbody_internal::multi_exchange_seconds(s->multi, positions, partial_sums);
+}
+
+extern "C" int nbody_mi355x_exchange_backend(nbody_mi355x_sim* s, int32_t* backend) {
+  if (!s || !backend) { set_error("exchange_backend: null argument"); return NBODY_MI355X_ERR_INVALID; }
+  *backend = !s->multi ? NBODY_MI355X_EXCHANGE_NONE
+                       : (nbody_internal::multi_uses_rccl(s->multi) ? NBODY_MI355X_EXCHANGE_RCCL : NBODY_MI355X_EXCHANGE_PEER_COPIES);
+  return NBODY_MI355X_OK;
+}
+
 extern "C" int nbody_mi355x_last_run_seconds(nbody_mi355x_sim* s, double* seconds) {
   if (!s || !seconds) { set_error("last_run_seconds: null argument"); return NBODY_MI355X_ERR_INVALID; }
   *seconds = s->last_run_seconds;

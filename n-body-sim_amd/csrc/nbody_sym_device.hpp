@@ -61,6 +61,11 @@ __device__ __forceinline__ float rotate_from_next_lane(float v) {
 __device__ __forceinline__ double fma_t(double a, double b, double c) { return __builtin_fma(a, b, c); }
 __device__ __forceinline__ float fma_t(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 
+// FP32 walks, scaled coordinates (the row's extent in [1, 2)): the bare cube y0^3 of a pair
+// closer than 2^-42 is beyond float's range (rsq(2^-84)^3 = 2^126).  Unsoftened, such a pair
+// counts as two bodies in one place and contributes nothing; softened, only d^2 == 0 does.
+constexpr float kMinR2f = 0x1p-84f;
+
 // The two weights of one pair from its separation: si = m_j r^-3 (applied to body i) and
 // sj = m_i r^-3 (applied to body j; only computed when WANT_J).
 // double: rsq seed + folded series, r^2 chain seeded with 2^-300 or eps2 (nbody_device.hpp).
@@ -88,9 +93,12 @@ __device__ __forceinline__ void pair_weights(double dx, double dy, double dz, do
 template <bool WANT_J>
 __device__ __forceinline__ void pair_weights(float dx, float dy, float dz, float mj, float mi, float eps2,
                                              float, float, float* si, float* sj) {
-  const float r2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, __builtin_fmaf(dx, dx, eps2)));
-  const float y = __builtin_amdgcn_rsqf(r2);
-  const float y0 = (r2 > 0.0f) ? y : 0.0f;
+  // the bare separation decides whether the pair counts: a body met with itself (or two in one
+  // place) has d2 == 0 whatever the softening, and must give 0, not (m inf) * 0; unsoftened,
+  // pairs closer than 2^-42 of the row's extent (kMinR2f) count as "in one place" too
+  const float d2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+  const float y = __builtin_amdgcn_rsqf(d2 + eps2);
+  const float y0 = (d2 > (eps2 > 0.0f ? 0.0f : kMinR2f)) ? y : 0.0f;
   const float y2 = y0 * y0;
   *si = (mj * y0) * y2;
   if (WANT_J) *sj = (mi * y0) * y2;
@@ -129,7 +137,6 @@ enum { kGeneral = 0, kDeferred = 1, kRowUnit = 2, kSameMass = 3 };
 // The j-side sums travel as TWO partial sums per component (even / odd bodies of the lane),
 // added when they are home.  Element for element the operations are the scalar path's
 // (IEEE fma / mul / add), in the same order on the i side.
-// SOFT: eps2 >= FLT_MIN, so r^2 > 0 for every pair and nothing has to be done about r^2 == 0.
 #ifndef NBODY_PK_W
 #define NBODY_PK_W 2
 #endif
@@ -147,7 +154,14 @@ __device__ __forceinline__ f2 splat(float v) { return f2{v, v}; }
 //                afterwards, discards them and walks again with kZeroSelect if one is not
 //                finite.  Off the diagonal tile that takes two bodies in one place (or
 //                input that is not finite, which then simply comes out again).
-enum { kZeroNone = 0, kZeroSelect = 1, kZeroRedo = 2 };
+//   kZeroSelectSoft  softened, where kZeroNone is not safe (below): the r^2 chain starts at 0, a
+//                pair with d^2 == 0 becomes +inf as above, every other gets d^2 + eps2: 3 a pair.
+// kZeroNone is only taken where the self pair's weight is certain to be finite (its separation
+// is exactly 0, and inf * 0 = NaN would poison the body's sum): the bare cube eps2'^-3/2 must
+// stay in range (eps2' >= kMinR2f in the row's scaled units) and no mass may multiply it
+// (kSameMass: the common mass is applied per sum, in double).  A scene with mixed masses in SI
+// units (m ~ 1e27 in the product) overflows long before that, so it takes kZeroSelectSoft.
+enum { kZeroNone = 0, kZeroSelect = 1, kZeroRedo = 2, kZeroSelectSoft = 3 };
 
 template <int H, bool SYM, int MODE, int ZERO>
 __device__ __forceinline__ void walk_pk(const P2<float>* xy, const P2<float>* zm, int gb, int lane,
@@ -183,7 +197,7 @@ __device__ __forceinline__ void walk_pk(const P2<float>* xy, const P2<float>* zm
           dz[k] = splat(jzm.x) - zi2[k0 + k];
         }
 #pragma unroll
-        for (int k = 0; k < W; k++) r2[k] = fma2(dx[k], dx[k], e2);
+        for (int k = 0; k < W; k++) r2[k] = ZERO == kZeroSelectSoft ? dx[k] * dx[k] : fma2(dx[k], dx[k], e2);
 #pragma unroll
         for (int k = 0; k < W; k++) r2[k] = fma2(dy[k], dy[k], r2[k]);
 #pragma unroll
@@ -191,8 +205,12 @@ __device__ __forceinline__ void walk_pk(const P2<float>* xy, const P2<float>* zm
 #pragma unroll
         for (int k = 0; k < W; k++) {
           if (ZERO == kZeroSelect) {
-            r2[k].x = (r2[k].x > 0.0f) ? r2[k].x : __builtin_inff();
-            r2[k].y = (r2[k].y > 0.0f) ? r2[k].y : __builtin_inff();
+            r2[k].x = (r2[k].x > kMinR2f) ? r2[k].x : __builtin_inff();
+            r2[k].y = (r2[k].y > kMinR2f) ? r2[k].y : __builtin_inff();
+          } else if (ZERO == kZeroSelectSoft) {
+            const f2 soft = r2[k] + e2;
+            r2[k].x = (r2[k].x > 0.0f) ? soft.x : __builtin_inff();
+            r2[k].y = (r2[k].y > 0.0f) ? soft.y : __builtin_inff();
           }
           y0[k] = f2{__builtin_amdgcn_rsqf(r2[k].x), __builtin_amdgcn_rsqf(r2[k].y)};
         }
@@ -234,7 +252,7 @@ __device__ __forceinline__ void walk_pk(const P2<float>* xy, const P2<float>* zm
   *fzo = fz;
 }
 
-template <int IPT, bool SYM, int MODE, bool SOFT>
+template <int IPT, bool SYM, int MODE, int SOFT>  // SOFT: 0 unsoftened, 1 kZeroNone is safe, 2 kZeroSelectSoft
 __device__ __forceinline__ void group_steps_pk(const P2<float>* xy, const P2<float>* zm, int gb, int lane,
                                                const float (&xi)[IPT], const float (&yi)[IPT],
                                                const float (&zi)[IPT], const float (&mi)[IPT], float (&ax)[IPT],
@@ -255,7 +273,7 @@ __device__ __forceinline__ void group_steps_pk(const P2<float>* xy, const P2<flo
   const f2 e2 = splat(eps2);
   f2 fx, fy, fz;
   // the diagonal tile meets every body with itself: selects from the start
-  constexpr int kFirst = SOFT ? kZeroNone : (SYM ? kZeroRedo : kZeroSelect);
+  constexpr int kFirst = SOFT == 1 ? kZeroNone : SOFT == 2 ? kZeroSelectSoft : (SYM ? kZeroRedo : kZeroSelect);
   walk_pk<H, SYM, MODE, kFirst>(xy, zm, gb, lane, xi2, yi2, zi2, mi2, gx, gy, gz, e2, &fx, &fy, &fz);
   if constexpr (kFirst == kZeroRedo) {
     f2 all = gx[0] + gy[0] + gz[0];  // finite iff every term is (inf - inf = NaN)
@@ -293,10 +311,13 @@ __device__ __forceinline__ void group_steps(const P2<T>* xy, const P2<T>* zm, in
                                             T (&ax)[IPT], T (&ay)[IPT], T (&az)[IPT], T eps2, T c15, T c1875,
                                             T inv_m_ref, T* fxo, T* fyo, T* fzo) {
   if constexpr (sizeof(T) == sizeof(float) && IPT % 2 == 0 && (MODE == kGeneral || MODE == kSameMass)) {  // FP32: packed
-    if (eps2 >= 1.17549435e-38f) {
-      group_steps_pk<IPT, SYM, MODE, true>(xy, zm, gb, lane, xi, yi, zi, mi, ax, ay, az, eps2, fxo, fyo, fzo);
+    if (eps2 > 0.0f) {  // softened: see kZeroNone / kZeroSelectSoft above
+      if (MODE == kSameMass && eps2 >= kMinR2f)
+        group_steps_pk<IPT, SYM, MODE, 1>(xy, zm, gb, lane, xi, yi, zi, mi, ax, ay, az, eps2, fxo, fyo, fzo);
+      else
+        group_steps_pk<IPT, SYM, MODE, 2>(xy, zm, gb, lane, xi, yi, zi, mi, ax, ay, az, eps2, fxo, fyo, fzo);
     } else {
-      group_steps_pk<IPT, SYM, MODE, false>(xy, zm, gb, lane, xi, yi, zi, mi, ax, ay, az, eps2, fxo, fyo, fzo);
+      group_steps_pk<IPT, SYM, MODE, 0>(xy, zm, gb, lane, xi, yi, zi, mi, ax, ay, az, eps2, fxo, fyo, fzo);
     }
     return;
   }

@@ -385,6 +385,14 @@ class ParticleSimulation {
     int rc = devs.size() > 1 ? nbody_mi355x_create_multi(&cfg, devs.data(), static_cast<int32_t>(devs.size()), &sim)
                              : nbody_mi355x_create(&cfg, &sim);
     if (rc != NBODY_MI355X_OK) return Failure(rc, nullptr);
+    if (devs.size() > 1 && !quiet_) {  // how the shards exchange, and the library's note if RCCL was not taken
+      int32_t backend = NBODY_MI355X_EXCHANGE_NONE;
+      const std::string note = nbody_mi355x_last_error();
+      if (nbody_mi355x_exchange_backend(sim, &backend) == NBODY_MI355X_OK)
+        std::cout << "MI355X: " << devs.size() << " shards, exchanges by "
+                  << (backend == NBODY_MI355X_EXCHANGE_RCCL ? "RCCL collectives (self-check passed)" : "peer copies")
+                  << (note.empty() ? "" : " -- ") << note << std::endl;
+    }
     rc = nbody_mi355x_upload(sim, state_[cur_].data(), mass_.data());
     if (rc != NBODY_MI355X_OK) return Failure(rc, sim);
     {  // say so when the library had to fall back to the slower kernel family

@@ -53,6 +53,7 @@ class StepArgs(C.Structure):
     ]
 
 
+EXCHANGE_NONE, EXCHANGE_PEER_COPIES, EXCHANGE_RCCL = 0, 1, 2
 VARIANT_WAVE, VARIANT_TINY = 7, 8
 STATIC_SCRATCH_BYTES = 134217728   # NBODY_MI355X_STATIC_SCRATCH_BYTES
 WAVE_MAX_BODIES = 4096   # NBODY_MI355X_WAVE_MAX_BODIES: below, whole FP64 steps take the wave kernels
@@ -101,6 +102,8 @@ SYMBOLS = {
     "nbody_mi355x_energy": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "nbody_mi355x_kernel_in_use": (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
     "nbody_mi355x_last_run_seconds": (C.c_int, [_P, C.POINTER(C.c_double)]),
+    "nbody_mi355x_last_exchange_seconds": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "nbody_mi355x_exchange_backend": (C.c_int, [_P, C.POINTER(C.c_int32)]),
     "nbody_mi355x_ic_plummer": (C.c_int, [C.c_int64, C.c_uint64, C.c_double, _P, _P]),
     "nbody_mi355x_ic_uniform_cube": (C.c_int, [C.c_int64, C.c_uint64, C.c_double, _P, _P]),
     "nbody_mi355x_ic_ring": (C.c_int, [C.c_int64, C.c_uint64] + [C.c_double] * 6 + [_P, _P]),
@@ -306,6 +309,18 @@ class Simulation:
         s = C.c_double()
         check(lib().nbody_mi355x_last_run_seconds(self._h, C.byref(s)))
         return s.value
+
+    def last_exchange_seconds(self):
+        """(positions, partial_sums): device seconds of the two exchanges of the last small step of the last run."""
+        a, b = C.c_double(), C.c_double()
+        check(lib().nbody_mi355x_last_exchange_seconds(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def exchange_backend(self) -> int:
+        """EXCHANGE_NONE (one device), EXCHANGE_PEER_COPIES or EXCHANGE_RCCL."""
+        v = C.c_int32()
+        check(lib().nbody_mi355x_exchange_backend(self._h, C.byref(v)))
+        return v.value
 
     def close(self) -> None:
         if getattr(self, "_h", None):

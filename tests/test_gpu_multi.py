@@ -115,10 +115,12 @@ def _rccl_one_rank_main(n, q):
     p, m = nb.ic_plummer(n, 13)
     with nb.Simulation(n, 1e-3, devices=[0]) as sim:
         text = nb.last_error()              # create leaves a note here if it fell back to peer copies
+        backend = sim.exchange_backend()
         sim.upload(p, m)
         outs = [sim.run(3, snapshot=True) for _ in range(2)]
+        seconds = sim.last_exchange_seconds()
         fin = sim.download()
-    q.put((text, outs, fin))
+    q.put((text, outs, fin, backend, seconds))
 
 
 @pytest.mark.parametrize("n", [1500, 20000])
@@ -131,10 +133,14 @@ def test_rccl_exchanges_with_a_one_rank_communicator(n):
     q = ctx.Queue()
     pr = ctx.Process(target=_rccl_one_rank_main, args=(n, q))
     pr.start()
-    text, outs, fin = q.get(timeout=200)
+    text, outs, fin, backend, seconds = q.get(timeout=200)
     pr.join(timeout=60)
     assert pr.exitcode == 0
-    assert "peer copies" not in text, text     # RCCL was loaded and the communicator built
+    # RCCL was loaded, the communicator built, and its SELF-CHECK at create passed (all-gather
+    # and reduce-scatter of a patterned buffer, bit for bit against the peer copies)
+    assert "peer copies" not in text, text
+    assert backend == nb.EXCHANGE_RCCL
+    assert seconds[0] > 0 and (seconds[1] > 0) == (n >= 2048), seconds   # the sums are exchanged on the pair-symmetric path only
     p, m = nb.ic_plummer(n, 13)
     fin_ref, ref = ol.simulate(p, m, 2, 3, 1e-3, threads=16)
     for k in range(2):
@@ -155,3 +161,29 @@ def test_multi_overlap_many_steps_bit_reproducible():
     assert np.array_equal(a, b) and np.array_equal(fin_a, fin_b)
     _, ref = ol.simulate(p, m, 2, 20, 1e-3, threads=16)
     assert rel_pos_err(a[1, :, :3], ref[1, :, :3]) <= 1e-12
+
+
+def test_exchange_backend_and_measured_exchange_cost():
+    """Which exchange a handle uses and what the two exchanges of a small step cost on the device
+    (nbody_mi355x_exchange_backend / _last_exchange_seconds): shards that share a GPU take the
+    event-ordered peer copies (RCCL needs a GPU per rank -- on a multi-GPU node it is the default
+    behind its self-check); a one-device handle exchanges nothing."""
+    n = 24000
+    p, m = nb.ic_plummer(n, 5)
+    with nb.Simulation(n, 1e-3, devices=[0, 0, 0, 0]) as sim:
+        assert sim.exchange_backend() == nb.EXCHANGE_PEER_COPIES
+        assert nb.last_error() == ""        # nothing to report: RCCL was not tried for shards sharing a GPU
+        sim.upload(p, m)
+        sim.run(4, snapshot=False)
+        pos_s, sums_s = sim.last_exchange_seconds()
+        step_s = sim.last_run_seconds() / 4
+    assert 0 < pos_s < step_s and 0 < sums_s < step_s
+    with nb.Simulation(1000, 1e-3, devices=[0, 0], variant=1) as sim:   # one-sided: positions only
+        sim.upload(*nb.ic_plummer(1000, 1))
+        sim.run(2, snapshot=False)
+        pos_s, sums_s = sim.last_exchange_seconds()
+    assert pos_s > 0 and sums_s == 0
+    with nb.Simulation(n, 1e-3) as sim:
+        sim.upload(p, m)
+        sim.run(1, snapshot=False)
+        assert sim.exchange_backend() == nb.EXCHANGE_NONE and sim.last_exchange_seconds() == (0.0, 0.0)

@@ -194,6 +194,25 @@ def test_config3_plummer_65536_full_trajectory():
     _, out = gpu_simulate(p, m, 1, 100, 1e-3)
     assert rel_pos_err(out[0, :, :3], ref[0, :, :3]) <= FP64_TOL
     assert rel_pos_err(out[0, :, :3], ref[0, :, :3]) <= 1e-11
+    # north_star's second gate at the config's full size: total-energy drift over the run within
+    # 1 % of the reference's, both energies by the checker's diagnostic (the oracle's trajectory
+    # is already in hand: its last snapshot against the GPU's last snapshot)
+    e0 = sum(ol.energy(p, m, threads=16))
+    drift_ref = sum(ol.energy(ref[0], m, threads=16)) - e0
+    drift_gpu = sum(ol.energy(out[0], m, threads=16)) - e0
+    assert drift_ref != 0 and abs(drift_gpu / drift_ref - 1) <= 0.01
+
+
+def test_fp32_full_trajectory_65536_against_oracle():
+    """The FP32 variant at BASELINE config 3's size: 100 small steps of Plummer N = 65 536 with
+    float pair arithmetic against the oracle's double AVX2 path (ref: particle_simulation.h:
+    248-322 / :382-544): inside north_star's 1e-4, and not the double kernel (> 1e-12)."""
+    n = 65536
+    p, m = nb.ic_plummer(n, 42)
+    _, ref = ol.simulate(p, m, 1, 100, 1e-3, threads=16, kind="avx2")
+    _, out = gpu_simulate(p, m, 1, 100, 1e-3, precision=nb.FP32)
+    err = rel_pos_err(out[0, :, :3], ref[0, :, :3])
+    assert 1e-12 < err <= FP32_TOL
 
 
 @pytest.mark.parametrize("n", [65536, 196609, 260096, 262144, 1048576])
@@ -214,6 +233,25 @@ def test_full_size_sampled_rows_and_momentum(n):
     f = (m[:, None] * out[:, 6:9]).sum(0)
     scale = (m * np.linalg.norm(out[:, 6:9], axis=1)).sum()
     assert np.linalg.norm(f) <= 1e-12 * scale
+
+
+def test_fp32_plummer_1m_sampled_rows_and_momentum():
+    """The workload of the FP32 headline figure (Plummer N = 1 048 576, float pair arithmetic):
+    exact accelerations of 1024 sampled rows from the oracle, within 1e-4 of the largest |a| --
+    and outside 1e-12, so it IS the float kernel --, momentum balance to float rounding, and
+    the positions after one step (double integration) exact functions of the ICs."""
+    n = 1048576
+    p, m = nb.ic_plummer(n, 42)
+    with nb.Simulation(n, 1e-3, precision=nb.FP32) as sim:
+        sim.upload(p, m)
+        out = sim.run(1, snapshot=True)
+    rows = np.random.default_rng(0).choice(n, 1024, replace=False)
+    acc = ol.accel_rows(p, m, rows, threads=16)
+    err = np.linalg.norm(out[rows, 6:9] - acc, axis=1).max() / np.linalg.norm(acc, axis=1).max()
+    assert 1e-12 < err <= FP32_ACC_TOL
+    np.testing.assert_allclose(out[:, 0:3], p[:, :3] + 1e-3 * p[:, 3:], rtol=1e-14, atol=1e-17)
+    f = (m[:, None] * out[:, 6:9]).sum(0)
+    assert np.linalg.norm(f) <= 1e-5 * (m * np.linalg.norm(out[:, 6:9], axis=1)).sum()
 
 
 @pytest.mark.parametrize("n,precision", [(262144, "fp64"), (4194304, "fp64"), (4194304, "fp32")])
