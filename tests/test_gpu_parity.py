@@ -425,6 +425,32 @@ def test_fp32_packed_walk_scales_softening_and_bodies_in_one_place(variant):
     assert np.abs(hard64[0, :, 6:9] - soft64[0, :, 6:9]).max() > 1e-2 * scale   # the softening is felt
 
 
+@pytest.mark.parametrize("variant", [0, 2, 11, 12, 18, 21, 24, 28])
+def test_fp32_tiny_or_si_softening_keeps_the_self_pair_finite(variant):
+    """a body met with itself has separation exactly 0, and in float its
+    weight m (eps2)^-3/2 overflows for a softening that is positive but small (1e-30 on a
+    unit-size scene), or modest with SI masses in the product (a ring around 5.7e26 kg, eps =
+    1 km): inf * 0 = NaN poisoned every body of the block.  The float walks now select on the
+    BARE separation wherever the weight is not certain to be finite.  Against the double
+    kernels with the same eps2 (variant 0: the library's own choice for a caller that allows
+    float); the softening is far below every real separation, so the answer is the unsoftened one."""
+    n = 9000
+    p, m = nb.ic_plummer(n, 12)
+    for eps2 in (1e-30, 1e-45, 3e-26):
+        _, ref = gpu_simulate(p, m, 1, 1, 1e-3, eps2=eps2)
+        _, out = gpu_simulate(p, m, 1, 1, 1e-3, eps2=eps2, precision=nb.FP32, variant=variant)
+        assert np.all(np.isfinite(out)), eps2
+        scale = np.linalg.norm(ref[0, :, 6:9], axis=1).max()
+        assert np.abs(out[0, :, 6:9] - ref[0, :, 6:9]).max() <= FP32_ACC_TOL * scale, eps2
+    p, m = nb.ic_ring(n, 42)                                  # SI units, mixed masses, the planet is body 0
+    for eps2 in (1e6, 1e-3):                                  # (1 km)^2; (3 cm)^2
+        _, ref = gpu_simulate(p, m, 1, 1, 0.01, eps2=eps2)
+        _, out = gpu_simulate(p, m, 1, 1, 0.01, eps2=eps2, precision=nb.FP32, variant=variant)
+        assert np.all(np.isfinite(out)), eps2
+        scale = np.linalg.norm(ref[0, :, 6:9], axis=1).max()
+        assert np.abs(out[0, :, 6:9] - ref[0, :, 6:9]).max() <= FP32_ACC_TOL * scale, eps2
+
+
 @pytest.mark.parametrize("devices", [None, [0, 0, 0]])
 def test_run_async_overlaps_and_matches_run(devices):
     """run_async + wait == run, big step after big step, with page-locked snapshot buffers
