@@ -82,8 +82,8 @@ __device__ __forceinline__ void tile_phases(const P2<T>* xy, const P2<T>* zm, T 
     const int grp = (ph + (ng >> 2) * w) % ng;  // the 4 waves sit on 4 different groups
     const int gb = grp * kGrp;
     T fx, fy, fz;
-    group_steps<IPT, SYM, MODE, T>(xy, zm, gb, lane, xi, yi, zi, mi, ax, ay, az, eps2, c15, c1875, inv_m_ref, &fx, &fy,
-                                   &fz);
+    group_steps<IPT, SYM, MODE, T>(xy, zm, gb, lane, xi, yi, zi, mi, ax, ay, az, eps2, c15, c1875, inv_m_ref, 0, 8, &fx,
+                                   &fy, &fz);
     if (SYM) {  // the sums are home: lane l holds body l of the group
       if constexpr (MODE == kDeferred) {
         fx *= m_ref;
@@ -269,11 +269,13 @@ __global__ __launch_bounds__(256) void sym_tiles_kernel(const SymArgs a) {
 // g = (slab, off), added in a fixed order: the own rows' i-side chunks R[r_first..nR) (own
 // slab only) and, for every own row I that met g's block J at a distance d = J - I (mod nb)
 // inside [max(d_lo,1), d_hi], the j-side sums C[d - c_base][I][.].
-// The list of partials is dealt over kParts threads per slot (part p takes every kParts-th
-// chunk and row), whose sums are then added in part order through LDS: 4x the loads in
-// flight on these memory-bound kernels (a slot has up to ~300 partials of 24 bytes), still one
-// fixed order of additions.
-constexpr int kParts = 4;
+// The list of partials is dealt over PARTS threads per slot (part p takes every PARTS-th
+// chunk and row), whose sums are then added in part order through LDS: more loads in flight on
+// these memory-bound kernels (a slot has up to ~300 partials of 24 bytes), still one fixed order
+// of additions.  PARTS by launch size (parts_for): a small system's finishing launch is one
+// round of waves whose time is the latency of its dependent loads -- 16 384 bodies: 41 partials
+// per slot, 4 parts: 6.9 us; 16 parts: every thread two or three loads deep.
+template <int PARTS>
 __device__ __forceinline__ void sum_partials(const SymArgs& sa, int slab, int64_t off, bool own_slab, int part,
                                              double* ax, double* ay, double* az) {
   const int64_t S = sa.S;
@@ -284,7 +286,7 @@ __device__ __forceinline__ void sum_partials(const SymArgs& sa, int slab, int64_
   // (unrolled so that several partials' loads are in flight; the order of the adds is unchanged)
   if (own_slab) {
 #pragma unroll 4
-    for (int s = sa.r_first + part; s < sa.nR; s += kParts) {
+    for (int s = sa.r_first + part; s < sa.nR; s += PARTS) {
       const double* Rs = sa.R + static_cast<int64_t>(s) * 3 * S + off;
       x += Rs[0];
       y += Rs[S];
@@ -293,7 +295,7 @@ __device__ __forceinline__ void sum_partials(const SymArgs& sa, int slab, int64_
   }
   const int d_min = sa.d_lo > 1 ? sa.d_lo : 1;
 #pragma unroll 4
-  for (int il = part; il < sa.nbs; il += kParts) {
+  for (int il = part; il < sa.nbs; il += PARTS) {
     const int I = sa.row0 + il;
     int d = J - I;
     if (d < 0) d += sa.nb;
@@ -302,14 +304,32 @@ __device__ __forceinline__ void sum_partials(const SymArgs& sa, int slab, int64_
     x += Cd[0];
     y += Cd[S];
     z += Cd[2 * S];
+    if (sa.q > 0) {
+      // wave tiles: was this entry of row I cut between two waves?  Its octets are [8 e, 8 e + 8)
+      // of the row's list; wave k begins at octet k q: the first boundary behind 8 e is that of
+      // wave k = floor(8 e / q) + 1, and it cuts the entry iff it falls before 8 e + 8 (and
+      // inside the row's list: the high rows' lists are shorter by the antipodal tile)
+      int dh = sa.d_hi;
+      if (2 * dh == sa.nb && I >= sa.nb / 2) dh--;
+      const unsigned o = 8u * static_cast<unsigned>(((d - sa.d_lo) << (sa.bshift - 6)) + (jl >> 6));
+      const unsigned k = __umulhi(o, sa.q_magic) + 1u;
+      const unsigned b = k * static_cast<unsigned>(sa.q);
+      if (b < o + 8u && b < static_cast<unsigned>((dh - sa.d_lo + 1) << (sa.bshift - 6)) * 8u) {
+        const double* Cb = sa.Cb + (static_cast<int64_t>(il) * sa.wstride + k) * 192 + (jl & 63);
+        x += Cb[0];
+        y += Cb[64];
+        z += Cb[128];
+      }
+    }
   }
   *ax = x; *ay = y; *az = z;
 }
 
-// The kParts partial sums of the workgroup's 64 slots, added in part order; valid for part 0.
-// blockDim = (64, kParts): threadIdx.x = slot within the workgroup, threadIdx.y = part.
+// The PARTS partial sums of the workgroup's 64 slots, added in part order; valid for part 0.
+// blockDim = (64, PARTS): threadIdx.x = slot within the workgroup, threadIdx.y = part.
+template <int PARTS>
 __device__ __forceinline__ void combine_parts(double* ax, double* ay, double* az) {
-  __shared__ double red[3][kParts][64];
+  __shared__ double red[3][PARTS][64];
   const int l = threadIdx.x, p = threadIdx.y;
   red[0][p][l] = *ax;
   red[1][p][l] = *ay;
@@ -318,7 +338,7 @@ __device__ __forceinline__ void combine_parts(double* ax, double* ay, double* az
   if (p == 0) {
     double x = red[0][0][l], y = red[1][0][l], z = red[2][0][l];
 #pragma unroll
-    for (int q = 1; q < kParts; q++) {
+    for (int q = 1; q < PARTS; q++) {
       x += red[0][q][l];
       y += red[1][q][l];
       z += red[2][q][l];
@@ -328,29 +348,31 @@ __device__ __forceinline__ void combine_parts(double* ax, double* ay, double* az
 }
 
 // one slab, one batch: the partial sums are the complete sums -> integrate directly
-__global__ __launch_bounds__(256) void sym_finish_kernel(const SymArgs sa, const nbody_mi355x_step_args a) {
+template <int PARTS>
+__global__ __launch_bounds__(64 * PARTS) void sym_finish_kernel(const SymArgs sa, const nbody_mi355x_step_args a) {
   const int64_t g = static_cast<int64_t>(blockIdx.x) * 64 + threadIdx.x;
   const bool real = g < a.own_count;
   const int64_t S = sa.S;
   double ax = 0.0, ay = 0.0, az = 0.0;
-  if (real) sum_partials(sa, 0, g, true, threadIdx.y, &ax, &ay, &az);
-  combine_parts(&ax, &ay, &az);
+  if (real) sum_partials<PARTS>(sa, 0, g, true, threadIdx.y, &ax, &ay, &az);
+  combine_parts<PARTS>(&ax, &ay, &az);
   if (real && threadIdx.y == 0)
     integrate_and_store(a, g, a.pos_cur[g], a.pos_cur[S + g], a.pos_cur[2 * S + g], ax, ay, az);
 }
 
 // several slabs (ranks) and/or several batches: this rank's partial sums of this batch for
 // EVERY slot into out[num_shards][3][S] (first batch: stored; later batches: added).
-__global__ __launch_bounds__(256) void sym_gather_kernel(const SymArgs sa, int own_shard, int num_shards,
-                                                         bool first, double* __restrict__ out) {
+template <int PARTS>
+__global__ __launch_bounds__(64 * PARTS) void sym_gather_kernel(const SymArgs sa, int own_shard, int num_shards,
+                                                                bool first, double* __restrict__ out) {
   const int64_t S = sa.S;
   const int64_t g = static_cast<int64_t>(blockIdx.x) * 64 + threadIdx.x;
   const bool real = g < S * num_shards;
   const int slab = real ? static_cast<int>(g / S) : 0;
   const int64_t off = real ? g - static_cast<int64_t>(slab) * S : 0;
   double ax = 0.0, ay = 0.0, az = 0.0;
-  if (real) sum_partials(sa, slab, off, slab == own_shard, threadIdx.y, &ax, &ay, &az);
-  combine_parts(&ax, &ay, &az);
+  if (real) sum_partials<PARTS>(sa, slab, off, slab == own_shard, threadIdx.y, &ax, &ay, &az);
+  combine_parts<PARTS>(&ax, &ay, &az);
   if (!real || threadIdx.y != 0) return;
   double* o = out + static_cast<int64_t>(slab) * 3 * S + off;
   if (first) {
@@ -362,6 +384,32 @@ __global__ __launch_bounds__(256) void sym_gather_kernel(const SymArgs sa, int o
     o[S] += ay;
     o[2 * S] += az;
   }
+}
+
+int env_int(const char* name) {  // tuning experiments only
+  const char* env = getenv(name);
+  return env ? atoi(env) : 0;
+}
+
+// threads per slot of the finishing kernels: enough waves to fill the chip with loads in flight
+// (1024 SIMDs x several waves), fewer parts where there are slots enough
+int parts_for(int64_t slots) {
+  if (const int v = env_int("NBODY_MI355X_SYM_PARTS"); v == 4 || v == 8 || v == 16) return v;  // (A/B tests)
+  return slots <= 32768 ? 16 : (slots <= 131072 ? 8 : 4);
+}
+void launch_finish(int parts, unsigned groups, hipStream_t stream, const SymArgs& sa, const nbody_mi355x_step_args& a) {
+  if (parts == 16) hipLaunchKernelGGL(sym_finish_kernel<16>, dim3(groups), dim3(64, 16), 0, stream, sa, a);
+  else if (parts == 8) hipLaunchKernelGGL(sym_finish_kernel<8>, dim3(groups), dim3(64, 8), 0, stream, sa, a);
+  else hipLaunchKernelGGL(sym_finish_kernel<4>, dim3(groups), dim3(64, 4), 0, stream, sa, a);
+}
+void launch_gather(int parts, unsigned groups, hipStream_t stream, const SymArgs& sa, int own_shard, int num_shards,
+                   bool first, double* out) {
+  if (parts == 16)
+    hipLaunchKernelGGL(sym_gather_kernel<16>, dim3(groups), dim3(64, 16), 0, stream, sa, own_shard, num_shards, first, out);
+  else if (parts == 8)
+    hipLaunchKernelGGL(sym_gather_kernel<8>, dim3(groups), dim3(64, 8), 0, stream, sa, own_shard, num_shards, first, out);
+  else
+    hipLaunchKernelGGL(sym_gather_kernel<4>, dim3(groups), dim3(64, 4), 0, stream, sa, own_shard, num_shards, first, out);
 }
 
 // one slab, several batches: integrate from the accumulated sums
@@ -377,8 +425,8 @@ __global__ __launch_bounds__(256) void sym_integrate_kernel(const double* __rest
 struct Plan {
   bool wave;  // wave tiles (nbody_symw.hip): blocks of 64 * ipt slots; else workgroup tiles: 256 * ipt
   int ipt, nbs, nb, D, dsplit, jsplit, jlocal;
-  int per;      // wave tiles: entries of a row's (tile, group) list per workgroup
-  int rchunks;  // R chunks the main launch writes per row (dsplit * jsplit / the list's chunks)
+  int rchunks;  // R chunks the main launch writes per row (dsplit * jsplit / wave tiles: workgroups per row)
+  int cbrows;   // wave tiles: rows of the workspace that hold Cb (second parts of cut entries)
   int64_t block;      // slots per block
   int64_t bytes;      // preferred workspace: every distance in one batch, capped (kBatchCap)
   int64_t row_bytes;  // 3 * S doubles: one R chunk / one distance of C / the batch accumulator
@@ -395,12 +443,7 @@ constexpr int64_t kBatchCap = int64_t{4} << 30;
 // rows of the workspace that are not C: R chunks (jlocal of phase 1 + the main launch's) and,
 // on one slab, the accumulator that batches add into
 int64_t fixed_rows(const Plan& p, int num_shards) {
-  return p.jlocal + static_cast<int64_t>(p.rchunks) + (num_shards == 1 ? 1 : 0);
-}
-
-int env_int(const char* name) {  // tuning experiments only
-  const char* env = getenv(name);
-  return env ? atoi(env) : 0;
+  return p.jlocal + static_cast<int64_t>(p.rchunks) + p.cbrows + (num_shards == 1 ? 1 : 0);
 }
 
 void plan_bytes(const nbody_mi355x_step_args& a, Plan* p) {
@@ -418,7 +461,7 @@ double plan_for(const nbody_mi355x_step_args& a, int ipt, Plan* p) {
   const int64_t B = 256 * ipt;
   if (a.num_shards < 1 || a.shard_slots <= 0 || a.shard_slots % B != 0) return -1.0;
   p->wave = false;
-  p->per = 0;
+  p->cbrows = 0;
   p->block = B;
   p->ipt = ipt;
   p->nbs = static_cast<int>(a.shard_slots / B);
@@ -462,23 +505,24 @@ double plan_for(const nbody_mi355x_step_args& a, int ipt, Plan* p) {
 }
 
 // The wave-tile kernels (nbody_symw.hip) with blocks of 64 * ipt slots.  A row's work is the
-// list of its (tile, group) entries -- (D+1) tiles of ipt groups of 64 j bodies -- cut into
-// chunks of `per` entries, one workgroup each, whose 4 waves (all holding the row's bodies)
-// take every fourth entry.  Every chunk costs an R row (24 bytes per slot) to store and to add
-// again, so few large chunks are cheaper -- until the launch stops tiling the chip: the full
-// workgroups are equal items handed to 256 CUs, and a last round that covers only part of them
-// costs a whole round (40 960 bodies, 512-body blocks: per = 8: 579 us, per = 48: 707 us).
-// `per` is chosen from the sweep profiles/r02_wave_tile_sweep.csv (tools/sweep_wave_plan.py: 23
-// sizes x 3 block sizes x 8 values of per):
-//   * where some per makes the number of full workgroups an exact multiple of 256 -- every
-//     power-of-two size, and e.g. 24 576 or 49 152 bodies -- the largest such per that still
-//     leaves two full workgroups per CU wins (16 384: per = 16, 65 536: per = 32 or 64,
-//     131 072: per = 64), else the largest with one per CU;
-//   * otherwise small items level the load: the largest per that still leaves
-//     kWaveMinWorkgroups workgroups (~12 per CU), at least 4.
-// Against the best of the sweep this rule loses 1.5 % on average and 5.5 % at worst; a
-// closed-form model of the rounds (round 2's first attempt) lost 3.5 % and 22 %.
-constexpr int kWaveMinWorkgroups = 3000;
+// list of its (tile, group) entries -- (D+1) tiles of ipt groups of 64 j bodies, 8 octets of
+// rotation steps each -- dealt in OCTETS to the 4 * chunks waves of the row's `chunks`
+// workgroups (all holding the row's bodies), so every wave of the launch has the same work to
+// within one octet (round 2 dealt whole entries: level only where they happened to divide
+// evenly over the chip).  What is left to choose is `chunks`, by a score fitted to a sweep on the
+// chip (tools/sweep_wave_plan.py -> profiles/r03_wave_tile_sweep.csv: 12 sizes x 3 block sizes x
+// 15 values of chunks; equal work items make the dispatch-round model accurate -- round 2's
+// whole-entry items defeated it):
+//   * U = wgs / (256 ceil(wgs / 256)), wgs = nbs * chunks: the share of the last dispatch round
+//     that is used -- the launch is level where wgs is (just under) a multiple of the 256 CUs;
+//   * octets / (4 chunks q), q = ceil(octets / (4 chunks)): what rounding a wave's share up to
+//     whole octets wastes;
+//   * - 0.0005 per chunk: an R row (24 bytes per slot) to store and to add again;
+//   * - 0.02 / rounds: the end of a launch of few, long work items is ragged (the two waves of
+//     a SIMD do not finish together), smaller items even it out;
+//   * - 0.01 under two workgroups per CU: a lone wave per SIMD leaves its loads exposed.
+// Against the best of the sweep this rule loses 0.5 % on average, 1.7 % at worst over the sizes
+// it decides.  NBODY_MI355X_SYMW_CHUNKS overrides it.
 constexpr int64_t kWaveTileMaxSlots = 262143;  // wave tiles up to here, workgroup tiles beyond
 bool plan_wave(const nbody_mi355x_step_args& a, int ipt, Plan* p) {
   const int64_t B = 64 * ipt;
@@ -492,25 +536,25 @@ bool plan_wave(const nbody_mi355x_step_args& a, int ipt, Plan* p) {
   if (nb < 2 || nb > (1 << 24)) return false;
   p->nb = static_cast<int>(nb);
   p->D = p->nb / 2;
-  const int64_t entries = static_cast<int64_t>(p->D + 1) * ipt;  // per row
+  const int64_t octets = static_cast<int64_t>(p->D + 1) * ipt * 8;  // per row (the low rows')
   constexpr int64_t kCUs = 256;
-  int64_t per = 0, per_one = 0;
-  for (int64_t c = 64; c >= 4 && per == 0; c -= 4) {  // an exact tiling of the chip?
-    const int64_t n_full = p->nbs * (entries / c);
-    if (n_full < kCUs || n_full % kCUs != 0) continue;
-    if (n_full >= 2 * kCUs) per = c;
-    else if (per_one == 0) per_one = c;
+  int best = 1;
+  double best_score = -1.0;
+  for (int c = 1; c <= 64; c++) {
+    const int64_t q = (octets + 4 * c - 1) / (4 * c);
+    if (q < 8) break;
+    const int64_t wgs = static_cast<int64_t>(p->nbs) * c;
+    const int64_t rounds = (wgs + kCUs - 1) / kCUs;
+    const double score = static_cast<double>(wgs) / static_cast<double>(kCUs * rounds) *
+                             (static_cast<double>(octets) / static_cast<double>(4 * c * q)) -
+                         0.0005 * c - 0.02 / static_cast<double>(rounds) - (wgs < 2 * kCUs ? 0.01 : 0.0);
+    if (score > best_score) best = c, best_score = score;
   }
-  if (per == 0) per = per_one;
-  if (per == 0) {  // no: small items
-    per = 64;
-    while (per > 4 && static_cast<int64_t>(p->nbs) * ((entries + per - 1) / per) < kWaveMinWorkgroups) per -= 4;
-  }
-  if (const int v = env_int("NBODY_MI355X_SYMW_PER"); v >= 4 && v % 4 == 0) per = v;
-  p->per = static_cast<int>(per);
-  p->rchunks = static_cast<int>((entries + per - 1) / per);
+  if (const int v = env_int("NBODY_MI355X_SYMW_CHUNKS"); v >= 1 && (octets + 4 * v - 1) / (4 * v) >= 8) best = v;
+  p->rchunks = best;
   p->dsplit = p->jsplit = 1;
-  p->jlocal = (ipt + 3) / 4;  // phase 1: the ipt entries of the diagonal tile, 4 per workgroup
+  p->jlocal = (ipt + 3) / 4;  // phase 1: the ipt entries of the diagonal tile, one per wave
+  p->cbrows = (4 * best + ipt - 1) / ipt;  // nbs * 4 chunks * 192 doubles in rows of 3 S = nbs * 192 ipt
   plan_bytes(a, p);
   return true;
 }
@@ -538,10 +582,11 @@ bool make_plan(const nbody_mi355x_step_args& a, Plan* p) {
   {
     const int64_t total = a.shard_slots * a.num_shards;
     if (total <= kWaveTileMaxSlots) {
-      // block size by system size (sweep: 256-body blocks win up to ~26 000 bodies -- 20 480:
-      // 158 us against 162 with 512 -- and 512-body blocks beyond -- 28 672: 295 against 300);
-      // a smaller block where the larger one does not divide the slab
-      for (int ipt = total < 26624 ? 4 : 8; ipt >= 1; ipt /= 2)
+      // block size by system size (round 3's sweep, with a row's list dealt in octets: 512-body
+      // blocks win from 16 384 bodies up -- 16 384: 104.6 us against 106.9 with 256; 24 576: 215.6 /
+      // 219.8 -- 256-body blocks below -- 12 288: 68.4 / 69.5); a smaller block where the larger
+      // one does not divide the slab
+      for (int ipt = total < 14336 ? 4 : 8; ipt >= 1; ipt /= 2)
         if (plan_wave(a, ipt, p)) return true;
     }
   }
@@ -584,6 +629,18 @@ hipError_t launch_tiles(const Plan& p, bool fp32, const SymArgs& sa, dim3 grid, 
          : p.ipt == 4 ? launch_wg_tiles<4, double>(sa, grid, stream) : launch_wg_tiles<8, double>(sa, grid, stream);
 }
 
+// wave tiles: `octets` of a row's list over the 4 * chunks waves of `chunks` workgroups: at
+// least 8 octets per wave (fewer workgroups if need be; returned), and the multiplier the
+// finishing kernels divide by q with -- exact for x q < 2^32 (x: an octet index, < 2^21)
+int set_octets(SymArgs* sa, int64_t octets, int chunks) {
+  while (chunks > 1 && (octets + 4 * chunks - 1) / (4 * chunks) < 8) chunks--;
+  int64_t q = (octets + 4 * chunks - 1) / (4 * chunks);
+  if (q < 8) q = 8;
+  sa->q = static_cast<int>(q);
+  sa->q_magic = static_cast<unsigned>((uint64_t{1} << 32) / static_cast<uint64_t>(q)) + 1u;
+  return chunks;
+}
+
 hipError_t launch(const Plan& p, SymArgs sa, const nbody_mi355x_step_args& a, hipStream_t stream, int batch,
                   double* accum) {
   hipError_t e = hipSuccess;
@@ -592,7 +649,7 @@ hipError_t launch(const Plan& p, SymArgs sa, const nbody_mi355x_step_args& a, hi
   // phase 2 = the rest, then output; phase 0 = both
   if (a.phase == 1) {
     sa.d_lo = 0; sa.d_hi = 0; sa.dsplit = 1; sa.jsplit = sa.jlocal; sa.r_base = 0; sa.c_base = 1;
-    sa.per = 4;
+    if (p.wave) set_octets(&sa, p.ipt * 8, sa.jlocal);  // (no j-side sums on the diagonal: nothing is cut)
     return launch_tiles(p, fp32, sa, p.wave ? dim3(sa.nbs, sa.jlocal, 1) : dim3(sa.nbs, 1, sa.jlocal), stream);
   }
   const int d_first = a.phase == 2 ? 1 : 0;
@@ -608,21 +665,22 @@ hipError_t launch(const Plan& p, SymArgs sa, const nbody_mi355x_step_args& a, hi
     sa.c_base = lo > 1 ? lo : 1;
     sa.r_first = (first && a.phase == 2) ? 0 : sa.jlocal;  // the local phase's chunks join the first batch
     dim3 grid(sa.nbs, sa.dsplit, sa.jsplit);
-    if (p.wave) {  // this launch's part of every row's list, `per` entries per workgroup
-      const int chunks = ((hi - lo + 1) * p.ipt + p.per - 1) / p.per;
+    if (p.wave) {  // this launch's part of every row's list over its share of the row's workgroups
+      const int64_t octets = static_cast<int64_t>(hi - lo + 1) * p.ipt * 8, all = static_cast<int64_t>(sa.D + 1) * p.ipt * 8;
+      int chunks = static_cast<int>((p.rchunks * octets + all - 1) / all);
+      chunks = chunks < 1 ? 1 : (chunks > p.rchunks ? p.rchunks : chunks);
+      chunks = set_octets(&sa, octets, chunks);
       grid = dim3(sa.nbs, chunks, 1);
       sa.nR = sa.r_base + chunks;
     }
     e = launch_tiles(p, fp32, sa, grid, stream);
     if (e != hipSuccess) return e;
+    const int64_t total = sa.S * a.num_shards;
     if (only && a.acc_out == nullptr) {
-      hipLaunchKernelGGL(sym_finish_kernel, dim3(static_cast<unsigned>((a.own_count + 63) / 64)),
-                         dim3(64, kParts), 0, stream, sa, a);
+      launch_finish(parts_for(a.own_count), static_cast<unsigned>((a.own_count + 63) / 64), stream, sa, a);
       return hipGetLastError();
     }
-    const int64_t total = sa.S * a.num_shards;
-    hipLaunchKernelGGL(sym_gather_kernel, dim3(static_cast<unsigned>((total + 63) / 64)), dim3(64, kParts), 0,
-                       stream, sa, a.own_shard, a.num_shards, first, out);
+    launch_gather(parts_for(total), static_cast<unsigned>((total + 63) / 64), stream, sa, a.own_shard, a.num_shards, first, out);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
   }
@@ -703,7 +761,8 @@ int sym_step(const nbody_mi355x_step_args& a, hipStream_t stream) {
   sa.pos = a.pos_cur;
   sa.mass = a.mass;
   sa.R = static_cast<double*>(a.workspace);
-  sa.C = sa.R + static_cast<int64_t>(p.jlocal + p.rchunks) * 3 * a.shard_slots;
+  sa.Cb = sa.R + static_cast<int64_t>(p.jlocal + p.rchunks) * 3 * a.shard_slots;
+  sa.C = sa.Cb + static_cast<int64_t>(p.cbrows) * 3 * a.shard_slots;
   double* accum = a.num_shards == 1 ? sa.C + batch * 3 * a.shard_slots : nullptr;
   sa.S = a.shard_slots;
   sa.nbs = p.nbs;
@@ -720,7 +779,10 @@ int sym_step(const nbody_mi355x_step_args& a, hipStream_t stream) {
   sa.eps2 = a.eps2;
   sa.bshift = 0;
   while ((int64_t{1} << sa.bshift) < p.block) sa.bshift++;
-  sa.per = p.per;
+  sa.trace = nullptr;
+  sa.q = 0;  // (wave tiles: set per launch, set_octets)
+  sa.q_magic = 0;
+  sa.wstride = 4 * p.rchunks;
   sa.no_eq = env_int("NBODY_MI355X_SYM_NOEQ") != 0 ? 1 : 0;  // tests: compare the two forms bit for bit
   const hipError_t e = launch(p, sa, a, stream, static_cast<int>(batch), accum);
   if (e != hipSuccess) {

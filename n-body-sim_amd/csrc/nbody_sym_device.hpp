@@ -33,8 +33,18 @@ struct SymArgs {
   int c_base;          // distance stored in row 0 of C for this batch
   int no_eq;           // 1: never take the equal-mass forms of the tile loop (tests)
   int bshift;          // log2 of the block size B (finishing kernels: block of a slot = off >> bshift)
-  int per;             // wave tiles only: entries (tile, group) of a row's list per workgroup (multiple of 4)
+  // wave tiles only.  A row's work in a launch is the list of its (tile, group) entries, 8
+  // "octets" (8 rotation steps) each; wave k of the row (4 per workgroup) takes octets
+  // [k q, (k+1) q) of it -- whole entries in the middle, PARTS of entries at the two ends:
+  int q;               // octets per wave, >= 8, so an entry is cut at most once
+  unsigned q_magic;    // floor(x / q) = (x * q_magic) >> 32 for every x the finishing kernels form
+  double* Cb;          // [nbs][wstride][3][64]: j-side sums of the SECOND part of a cut entry, by
+                       // the wave that computed it (the first part goes to C like a whole entry)
+  int wstride;         // waves per row in Cb's indexing (4 * chunks of the largest launch)
   double eps2;
+  // tuning only (NBODY_MI355X_SYMW_TRACE, nbody_symw.hip): per workgroup {start, end (100 MHz
+  // clock), HW_ID, XCC_ID}; nullptr in every normal launch
+  unsigned long long* trace;
 };
 
 // a pair of coordinates as staged in LDS: {x,y} and {z,m}, in the arithmetic type
@@ -167,17 +177,17 @@ template <int H, bool SYM, int MODE, int ZERO>
 __device__ __forceinline__ void walk_pk(const P2<float>* xy, const P2<float>* zm, int gb, int lane,
                                         const f2 (&xi2)[H], const f2 (&yi2)[H], const f2 (&zi2)[H],
                                         const f2 (&mi2)[H], f2 (&ax2)[H], f2 (&ay2)[H], f2 (&az2)[H], f2 e2,
-                                        f2* fxo, f2* fyo, f2* fzo) {
+                                        int k0, int k1, f2* fxo, f2* fyo, f2* fzo) {
   // W packed pairs go through each stage together: neighbours in the instruction stream are
   // then independent (a packed result is not ready for the very next instruction), at W
   // times the live temporaries
   constexpr int W = H >= NBODY_PK_W ? NBODY_PK_W : H;
   f2 fx = {0, 0}, fy = {0, 0}, fz = {0, 0};
-  int rot = lane;
+  int rot = (lane + 8 * k0) & 63;
   P2<float> bxy[2], bzm[2];
   bxy[0] = xy[gb + rot];
   bzm[0] = zm[gb + rot];
-  for (int t8 = 0; t8 < 8; t8++) {
+  for (int t8 = k0; t8 < k1; t8++) {
     const int rot_next = (rot + 8) & 63;
     const P2<float>* pxy = xy + gb + rot;
     const P2<float>* pzm = zm + gb + rot;
@@ -256,8 +266,8 @@ template <int IPT, bool SYM, int MODE, int SOFT>  // SOFT: 0 unsoftened, 1 kZero
 __device__ __forceinline__ void group_steps_pk(const P2<float>* xy, const P2<float>* zm, int gb, int lane,
                                                const float (&xi)[IPT], const float (&yi)[IPT],
                                                const float (&zi)[IPT], const float (&mi)[IPT], float (&ax)[IPT],
-                                               float (&ay)[IPT], float (&az)[IPT], float eps2, float* fxo,
-                                               float* fyo, float* fzo) {
+                                               float (&ay)[IPT], float (&az)[IPT], float eps2, int k0, int k1,
+                                               float* fxo, float* fyo, float* fzo) {
   static_assert(IPT % 2 == 0, "two bodies per packed instruction");
   static_assert(MODE == kGeneral || MODE == kSameMass, "the float forms");
   constexpr int H = IPT / 2;
@@ -274,7 +284,7 @@ __device__ __forceinline__ void group_steps_pk(const P2<float>* xy, const P2<flo
   f2 fx, fy, fz;
   // the diagonal tile meets every body with itself: selects from the start
   constexpr int kFirst = SOFT == 1 ? kZeroNone : SOFT == 2 ? kZeroSelectSoft : (SYM ? kZeroRedo : kZeroSelect);
-  walk_pk<H, SYM, MODE, kFirst>(xy, zm, gb, lane, xi2, yi2, zi2, mi2, gx, gy, gz, e2, &fx, &fy, &fz);
+  walk_pk<H, SYM, MODE, kFirst>(xy, zm, gb, lane, xi2, yi2, zi2, mi2, gx, gy, gz, e2, k0, k1, &fx, &fy, &fz);
   if constexpr (kFirst == kZeroRedo) {
     f2 all = gx[0] + gy[0] + gz[0];  // finite iff every term is (inf - inf = NaN)
 #pragma unroll
@@ -283,7 +293,7 @@ __device__ __forceinline__ void group_steps_pk(const P2<float>* xy, const P2<flo
     if (__builtin_expect(__any(!(probe - probe == 0.0f)), 0)) {
 #pragma unroll
       for (int k = 0; k < H; k++) gx[k] = gy[k] = gz[k] = f2{0, 0};
-      walk_pk<H, SYM, MODE, kZeroSelect>(xy, zm, gb, lane, xi2, yi2, zi2, mi2, gx, gy, gz, e2, &fx, &fy, &fz);
+      walk_pk<H, SYM, MODE, kZeroSelect>(xy, zm, gb, lane, xi2, yi2, zi2, mi2, gx, gy, gz, e2, k0, k1, &fx, &fy, &fz);
     }
   }
 #pragma unroll
@@ -301,6 +311,9 @@ __device__ __forceinline__ void group_steps_pk(const P2<float>* xy, const P2<flo
 // step t the lane meets body (lane + t) mod 64 of the group.  SYM: the j-side sums travel
 // with their body through the lanes, one DPP wave rotation per step (6 v_mov_b32_dpp, 3.3
 // cycles each, per IPT pairs); 64 rotations later they are home: lane l holds body l's.
+// [k0, k1) selects a part of the walk in octets (8 steps each; the whole walk is [0, 8)): steps
+// 8 k0 .. 8 k1 - 1, after which lane l holds the sums of body (l + 8 k1) mod 64 over those steps
+// (the wave tiles cut an entry between two waves to level the load, nbody_symw.hip).
 // (Sending each step's sums to the body's LDS entry with a return-less ds_add_f64 instead
 // was tried: it removes the moves, but an LDS atomic with 64-bit data holds up the SIMD's
 // VALU issue for ~12 cycles, 3 of them cost more than the 6 moves -- tools/ubench_lds.hip,
@@ -309,26 +322,26 @@ template <int IPT, bool SYM, int MODE, typename T>
 __device__ __forceinline__ void group_steps(const P2<T>* xy, const P2<T>* zm, int gb, int lane, const T (&xi)[IPT],
                                             const T (&yi)[IPT], const T (&zi)[IPT], const T (&mi)[IPT],
                                             T (&ax)[IPT], T (&ay)[IPT], T (&az)[IPT], T eps2, T c15, T c1875,
-                                            T inv_m_ref, T* fxo, T* fyo, T* fzo) {
+                                            T inv_m_ref, int k0, int k1, T* fxo, T* fyo, T* fzo) {
   if constexpr (sizeof(T) == sizeof(float) && IPT % 2 == 0 && (MODE == kGeneral || MODE == kSameMass)) {  // FP32: packed
     if (eps2 > 0.0f) {  // softened: see kZeroNone / kZeroSelectSoft above
       if (MODE == kSameMass && eps2 >= kMinR2f)
-        group_steps_pk<IPT, SYM, MODE, 1>(xy, zm, gb, lane, xi, yi, zi, mi, ax, ay, az, eps2, fxo, fyo, fzo);
+        group_steps_pk<IPT, SYM, MODE, 1>(xy, zm, gb, lane, xi, yi, zi, mi, ax, ay, az, eps2, k0, k1, fxo, fyo, fzo);
       else
-        group_steps_pk<IPT, SYM, MODE, 2>(xy, zm, gb, lane, xi, yi, zi, mi, ax, ay, az, eps2, fxo, fyo, fzo);
+        group_steps_pk<IPT, SYM, MODE, 2>(xy, zm, gb, lane, xi, yi, zi, mi, ax, ay, az, eps2, k0, k1, fxo, fyo, fzo);
     } else {
-      group_steps_pk<IPT, SYM, MODE, 0>(xy, zm, gb, lane, xi, yi, zi, mi, ax, ay, az, eps2, fxo, fyo, fzo);
+      group_steps_pk<IPT, SYM, MODE, 0>(xy, zm, gb, lane, xi, yi, zi, mi, ax, ay, az, eps2, k0, k1, fxo, fyo, fzo);
     }
     return;
   }
   T fx = 0, fy = 0, fz = 0;
-  int rot = lane;
+  int rot = (lane + 8 * k0) & 63;
   // the body of the NEXT step is read while this step's pairs are evaluated: two register
   // sets used alternately (8 steps per trip: the roles are the same at every trip's start)
   P2<T> bxy[2], bzm[2];
   bxy[0] = xy[gb + rot];
   bzm[0] = zm[gb + rot];
-  for (int t8 = 0; t8 < 8; t8++) {
+  for (int t8 = k0; t8 < k1; t8++) {
     const int rot_next = (rot + 8) & 63;
     const P2<T>* pxy = xy + gb + rot;
     const P2<T>* pzm = zm + gb + rot;

@@ -9,22 +9,30 @@
 //     row in registers (IPT bodies per lane), so IPT -- the number of pairs one LDS read and
 //     one set of DPP moves serve -- no longer fixes the size of a work item;
 //   * the work of row I is the list of its (tile, group) entries: tiles (I, I+d), d = 0 .. D,
-//     each IPT groups of 64 j bodies.  Workgroup (I, c) takes `per` consecutive entries, its
-//     wave w every fourth of them.  A wave stages its group in its OWN 72 LDS entries (no
-//     workgroup barrier anywhere in the loop), walks it in 64 rotation steps (group_steps)
-//     and STORES the group's j-side sums straight to C[d][I][group] -- each (row, group) pair
-//     is met by exactly one wave, so nothing is added across waves on the j side;
+//     each IPT groups of 64 j bodies, each group a walk of 64 rotation steps = 8 OCTETS.  The
+//     list is dealt to the row's waves (4 per workgroup, `chunks` workgroups per row) in octets:
+//     wave k takes octets [k q, (k+1) q) -- whole entries in the middle and a PART of an entry
+//     at either end (q >= 8: an entry is cut at most once).  With whole entries per wave a
+//     launch is level only where the entries happen to divide evenly over the chip's SIMDs
+//     (16 384 bodies: 8.125 entries per SIMD -> some do 9: 10 % lost; round 2's sizes between
+//     the powers of two 3-8 % under their neighbours); in octets every wave has the same work
+//     to 1/8 entry.  A wave stages its group in its OWN 72 LDS entries (no workgroup barrier
+//     anywhere in the loop), walks its part of it (group_steps) and STORES the group's j-side
+//     sums -- to C[d][I][group] (whole entries and first parts) or, for the second part of a
+//     cut entry, to Cb[I][wave]; after steps [8 k0, 8 k1) lane l holds body (l + 8 k1) mod 64;
 //   * the i-side sums of the 4 waves are added through LDS in wave order at the end and
 //     stored once per workgroup to R[c][I].
-// Work items are 64 x 64*IPT pairs (3 .. 21 microseconds) instead of whole tiles; how many a
-// workgroup takes (`per`) and the block size come from a model of the launch (plan_wave,
-// nbody_sym.hip).
+// How many workgroups a row gets (`chunks`) comes from a model of the launch (plan_wave,
+// nbody_sym.hip): equal work items make the dispatch-round model exact.
 // The price is C traffic that grows as N^2 / (64*IPT) (each j sum is stored after meeting
 // 64*IPT bodies instead of 256*IPT): that is why the large systems keep workgroup tiles.
 // No atomics: bit-reproducible run to run.
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
 
 #include "nbody_sym_device.hpp"
 
@@ -85,6 +93,12 @@ __global__ __launch_bounds__(256) void sym_wave_kernel(const SymArgs a) {
   const int64_t S = a.S;
   T c15 = static_cast<T>(1.5), c1875 = static_cast<T>(1.875);
   asm volatile("" : "+v"(c15), "+v"(c1875));
+  if (a.trace != nullptr && tid == 0) {  // (tuning runs only: where and when this workgroup ran)
+    unsigned long long* t = a.trace + 4 * (static_cast<size_t>(c) * gridDim.x + il);
+    t[0] = wall_clock64();
+    t[2] = __builtin_amdgcn_s_getreg((4) | (31 << 11));   // HW_REG_HW_ID
+    t[3] = __builtin_amdgcn_s_getreg((20) | (31 << 11));  // HW_REG_XCC_ID
+  }
 
   T xi[IPT], yi[IPT], zi[IPT], mi[IPT], ax[IPT], ay[IPT], az[IPT];
   double ox = 0.0, oy = 0.0, oz = 0.0, sc = 1.0;  // float only: origin and scale, see wave_origin
@@ -125,16 +139,22 @@ __global__ __launch_bounds__(256) void sym_wave_kernel(const SymArgs a) {
   const double stage_m = 1.0 / m_unit;
   const double unit_i = sc * sc * m_unit;
 
-  // this launch's part of the row's list: distances d_lo .. dh, IPT entries each
+  // this launch's part of the row's list: distances d_lo .. dh, IPT entries of 8 octets each;
+  // this wave's octets of it (wave-uniform: kept in scalar registers)
   int dh = a.d_hi;
   if (2 * dh == a.nb && I >= a.nb / 2) dh--;  // the antipodal tile belongs to the low rows
-  const int n_entries = (dh - a.d_lo + 1) * IPT;
-  const int e_begin = c * a.per;
-  const int e_end = e_begin + a.per < n_entries ? e_begin + a.per : n_entries;
+  const int n_octets = (dh - a.d_lo + 1) * IPT * 8;
+  const int wr = __builtin_amdgcn_readfirstlane(c * 4 + w);  // this wave among the row's
+  int o_begin = wr * a.q, o_end = o_begin + a.q;
+  if (o_begin > n_octets) o_begin = n_octets;
+  if (o_end > n_octets) o_end = n_octets;
 
   P2<T>* wxy = xy[w];
   P2<T>* wzm = zm[w];
-  for (int e = e_begin + w; e < e_end; e += 4) {
+  for (int o = o_begin; o < o_end;) {
+    const int e = o >> 3, k0 = o & 7;                        // entry, first octet of it taken here
+    const int k1 = o_end - 8 * e < 8 ? o_end - 8 * e : 8;    // one past the last
+    o = 8 * e + k1;
     const int d = a.d_lo + e / IPT, g = e % IPT;
     int J = I + d;
     if (J >= a.nb) J -= a.nb;
@@ -163,8 +183,8 @@ __global__ __launch_bounds__(256) void sym_wave_kernel(const SymArgs a) {
 
     T fx = 0, fy = 0, fz = 0;
 #define NBODY_GROUP(SYM_, MODE_)                                                                                  \
-  group_steps<IPT, SYM_, MODE_, T>(wxy, wzm, 0, lane, xi, yi, zi, mi, ax, ay, az, eps2, c15, c1875, inv_m_ref, &fx, \
-                                   &fy, &fz)
+  group_steps<IPT, SYM_, MODE_, T>(wxy, wzm, 0, lane, xi, yi, zi, mi, ax, ay, az, eps2, c15, c1875, inv_m_ref, k0, \
+                                   k1, &fx, &fy, &fz)
     if (d != 0) {
       if (kDouble) {
         if (equal_mass) {
@@ -181,17 +201,23 @@ __global__ __launch_bounds__(256) void sym_wave_kernel(const SymArgs a) {
         if (equal_mass) NBODY_GROUP(true, kSameMass);
         else NBODY_GROUP(true, kGeneral);
       }
-      // 64 rotations later the sums are home: lane l holds body l of the group
-      double* Cd = a.C + static_cast<int64_t>(d - a.c_base) * 3 * S + static_cast<int64_t>(il) * B;
+      // the sums of the steps walked: lane l holds those of body (l + 8 k1) mod 64 of the group
+      // (a whole walk, or one that ends with the entry: its own body l).  A part that BEGINS
+      // the entry goes where a whole entry's sums go, C[d][I][group]; a part that begins
+      // inside it is the second part of a cut entry: Cb[I][this wave]
+      const int body = (lane + 8 * k1) & 63;
+      double* out = k0 == 0 ? a.C + static_cast<int64_t>(d - a.c_base) * 3 * S + static_cast<int64_t>(il) * B + g * 64
+                            : a.Cb + (static_cast<int64_t>(il) * a.wstride + wr) * 192;
+      const int64_t stride = k0 == 0 ? S : 64;
       if constexpr (kDouble) {
-        Cd[idx] = fx;
-        Cd[S + idx] = fy;
-        Cd[2 * S + idx] = fz;
+        out[body] = fx;
+        out[stride + body] = fy;
+        out[2 * stride + body] = fz;
       } else {  // out of the scaled units (of the common mass too where the group had it)
         const double unit_j = sc * sc * (equal_mass ? static_cast<double>(m_ref) : 1.0);
-        Cd[idx] = fx * unit_j;
-        Cd[S + idx] = fy * unit_j;
-        Cd[2 * S + idx] = fz * unit_j;
+        out[body] = fx * unit_j;
+        out[stride + body] = fy * unit_j;
+        out[2 * stride + body] = fz * unit_j;
       }
     } else {  // a group of the row's own block: i side only, every ordered pair
       if (kDouble && row_uniform) NBODY_GROUP(false, kRowUnit);
@@ -238,6 +264,7 @@ __global__ __launch_bounds__(256) void sym_wave_kernel(const SymArgs a) {
       Rs[2 * S + idx] = z;
     }
   }
+  if (a.trace != nullptr && tid == 0) a.trace[4 * (static_cast<size_t>(c) * gridDim.x + il) + 1] = wall_clock64();
 }
 
 template <int IPT, typename T>
@@ -248,7 +275,39 @@ hipError_t launch_one(const SymArgs& sa, dim3 grid, hipStream_t stream) {
 
 }  // namespace
 
-hipError_t launch_wave_tiles(int ipt, bool fp32, const SymArgs& sa, dim3 grid, hipStream_t stream) {
+// NBODY_MI355X_SYMW_TRACE=FILE (tuning only): every wave-tile launch is followed by a
+// synchronisation and appends one line per workgroup to FILE:
+//   launch  row  chunk  start  end (100 MHz ticks)  HW_ID  XCC_ID
+// -- where the dispatcher put each workgroup and when it ran.  Allocates, blocks the host: never
+// set it in a measured run.
+hipError_t launch_wave_tiles_plain(int ipt, bool fp32, const SymArgs& sa, dim3 grid, hipStream_t stream);
+hipError_t launch_wave_tiles(int ipt, bool fp32, const SymArgs& sa_in, dim3 grid, hipStream_t stream) {
+  SymArgs sa = sa_in;
+  sa.trace = nullptr;
+  const char* path = getenv("NBODY_MI355X_SYMW_TRACE");
+  if (path == nullptr || path[0] == 0) return launch_wave_tiles_plain(ipt, fp32, sa, grid, stream);
+  static int launch_no = 0;
+  const size_t count = static_cast<size_t>(grid.x) * grid.y;
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(&sa.trace), count * 4 * sizeof(unsigned long long));
+  if (e != hipSuccess) return e;
+  e = launch_wave_tiles_plain(ipt, fp32, sa, grid, stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(stream);
+  if (e == hipSuccess) {
+    std::vector<unsigned long long> h(count * 4);
+    e = hipMemcpy(h.data(), sa.trace, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    if (FILE* f = e == hipSuccess ? fopen(path, "a") : nullptr) {
+      for (size_t k = 0; k < count; k++)
+        fprintf(f, "%d %zu %zu %llu %llu %llu %llu\n", launch_no, k % grid.x, k / grid.x, h[4 * k], h[4 * k + 1], h[4 * k + 2],
+                h[4 * k + 3]);
+      fclose(f);
+    }
+  }
+  launch_no++;
+  (void)hipFree(sa.trace);
+  return e;
+}
+
+hipError_t launch_wave_tiles_plain(int ipt, bool fp32, const SymArgs& sa, dim3 grid, hipStream_t stream) {
   if (fp32) {
     switch (ipt) {
       case 1: return launch_one<1, float>(sa, grid, stream);

@@ -19,7 +19,8 @@ import numpy as np
 
 PKG_DIR = Path(__file__).resolve().parent
 ROOT = PKG_DIR.parent  # n-body-sim_amd/
-LIB_PATH = ROOT / "lib" / "libnbody_mi355x.so"
+# (NBODY_MI355X_LIB: another build of the same ABI, for A/B measurements on one GPU lease)
+LIB_PATH = Path(os.environ["NBODY_MI355X_LIB"]) if os.environ.get("NBODY_MI355X_LIB") else ROOT / "lib" / "libnbody_mi355x.so"
 
 TILE = 256
 G_REFERENCE = 6.7430e-11  # reference: particle_simulation.h:713

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """The data behind the launch model of the wave tiles (csrc/nbody_sym.hip: plan_wave): microseconds per
-small step for every (bodies, block = 64 * ipt, entries per workgroup) of a grid, equal masses, FP64.
-    python tools/sweep_wave_plan.py > profiles/r02_wave_tile_sweep.csv"""
+small step for every (bodies, block = 64 * ipt, workgroups per row) of a grid, equal masses, FP64.
+(Round 2 swept entries per workgroup, NBODY_MI355X_SYMW_PER: profiles/r02_wave_tile_sweep.csv; since
+round 3 a row's list is dealt in octets and the knob is the number of workgroups per row.)
+    python tools/sweep_wave_plan.py [sizes] > profiles/r03_wave_tile_sweep.csv"""
 import os
 import sys
 from pathlib import Path
@@ -12,14 +14,16 @@ import nbody_mi355x as nb  # noqa: E402
 
 SIZES = [5120, 6144, 7168, 8192, 9216, 10240, 12288, 14336, 16384, 18432, 20480, 24576, 28672, 32768, 36864,
          40960, 45056, 49152, 57344, 65536, 81920, 98304, 131072]
-PERS = [4, 8, 12, 16, 24, 32, 48, 64]
-print("bodies,ipt,per,us_per_step")
+CHUNKS = [1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 20, 24, 32, 48, 64]
+if len(sys.argv) > 1:
+    SIZES = [int(x) for x in sys.argv[1].split(",")]
+print("bodies,ipt,chunks,us_per_step")
 for n in SIZES:
     p, m = nb.ic_plummer(n, 42)
     steps = max(3, min(300, int(1.5e12 / (float(n) * n))))
     for ipt in (2, 4, 8):
-        for per in PERS:
-            os.environ["NBODY_MI355X_SYMW_PER"] = str(per)
+        for per in CHUNKS:
+            os.environ["NBODY_MI355X_SYMW_CHUNKS"] = str(per)
             try:
                 with nb.Simulation(n, 1e-3, variant=20 + ipt) as sim:
                     sim.upload(p, m)
