@@ -183,6 +183,16 @@ def other_configs(nb):
     out["config4_plummer_n1048576_fp64_general_masses"] = {
         "value": round(g, 1), "unit": "Ginteractions/s", "frac_general_masses": frac(g),
         "ms_per_step": round(t[2] * 1e3, 3), "repetitions": 5, "statistic": "median"}
+    # config 4 with the opt-in FP64_FAST tier (the correction series of r^-3 cut after its linear
+    # term: 17 instead of 18 operations per pair; NOT the parity path, include/nbody_mi355x.h)
+    with nb.Simulation(n, 1e-3, precision=nb.FP64_FAST) as sim:
+        sim.upload(p, m)
+        sim.run(1, snapshot=False)
+        t = _timed_runs(sim, 1, 5)
+    g = _gint(n, 1, t[2])
+    out["config4_plummer_n1048576_fp64_fast_tier"] = {
+        "value": round(g, 1), "unit": "Ginteractions/s", "frac": frac(g), "ms_per_step": round(t[2] * 1e3, 3),
+        "repetitions": 5, "statistic": "median", "note": "opt-in precision tier, <= 2.7e-14 per pair; not the headline"}
     # config 5 on one GPU: uniform cube N = 4 194 304, fp64 and FP32 forces
     n = 4194304
     p, m = nb.ic_uniform_cube(n, 7)
@@ -251,7 +261,7 @@ def verify_run(args, sim, nb, dist, world, rank, steps_done, ics, dt, prec, inte
     calls it); the result dict is returned on rank 0, None elsewhere."""
     import numpy as np
     n = sim.n
-    tol = VERIFY_TOL["f64" if prec == nb.FP64 else "f32"]
+    tol = VERIFY_TOL["f32" if prec == nb.FP32 else "f64"]
     use_dist = dist is not None and dist.is_initialized()
     masses = sim.all_masses()                    # (n,) host copy of what the device holds
     pos_before = sim.all_positions()             # every slab made current first (collective)
@@ -438,7 +448,8 @@ def main():
     ap.add_argument("--ic", choices=["plummer", "cube"], default="plummer",
                     help="plummer: BASELINE configs 3/4 (seed 42, dt 1e-3); cube: config 5 (uniform cube, seed 7, dt 1e-4)")
     ap.add_argument("--variant", type=int, default=0)
-    ap.add_argument("--precision", choices=["fp64", "fp32"], default="fp64")
+    ap.add_argument("--precision", choices=["fp64", "fp32", "fp64fast"], default="fp64",
+                    help="fp64 = the parity path (the headline); fp32 / fp64fast = the optional tiers of include/nbody_mi355x.h")
     ap.add_argument("--integrator", choices=["euler", "kick_drift", "kdk"], default="euler",
                     help="euler = the reference's (the headline); kdk = leapfrog, one more O(N) kernel per step")
     ap.add_argument("--device-ics", action="store_true",
@@ -499,7 +510,7 @@ def main():
             dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     n, K, W = args.n, args.steps, args.warmup
-    prec = nb.FP64 if args.precision == "fp64" else nb.FP32
+    prec = {"fp64": nb.FP64, "fp32": nb.FP32, "fp64fast": nb.FP64_FAST}[args.precision]
     if args.device_ics:                               # every rank makes the bodies it holds, on its GPU
         kind, seed, dt = (nb.SCENE_PLUMMER, 42, 1e-3) if args.ic == "plummer" else (nb.SCENE_UNIFORM_CUBE, 7, 1e-4)
         p, m = nb.make_scene(kind, n, seed=seed), None
@@ -585,9 +596,9 @@ def main():
             except Exception:
                 traffic = None
         uses_sym = sim.workspace is not None and args.variant in (0,) + nb.SYM_VARIANTS and not (
-            args.variant == 0 and world == 1 and prec == nb.FP64 and n <= nb.WAVE_MAX_BODIES)
+            args.variant == 0 and world == 1 and prec != nb.FP32 and n <= nb.WAVE_MAX_BODIES)
         kernel_label = ("pair-symmetric tiles + finish" if uses_sym else
-                        "one-sided step_wave_kernel" if (world == 1 and prec == nb.FP64 and n <= nb.WAVE_MAX_BODIES
+                        "one-sided step_wave_kernel" if (world == 1 and prec != nb.FP32 and n <= nb.WAVE_MAX_BODIES
                                                          and args.variant in (0, 7)) else "one-sided step_kernel")
         # a step may walk the block distances in batches (one launch of the tile kernel each)
         launches = 1
@@ -600,7 +611,7 @@ def main():
             "metric": "Ginteractions/s at N=1M fp64, 1/2/4/8 MI355X; % of FP64 vector peak",
             "value": round(value, 2), "unit": "Ginteractions/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": round(wall / K * 1e3, 3), "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "f64" if prec == nb.FP64 else "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32" if prec == nb.FP32 else "f64", "data": "synthetic",
             "config": {"workload": scene,
                        "bodies": n, "interactions_per_step": inter_per_step,
                        "parallelism": ("one GPU, no collective" if not use_dist else
@@ -611,7 +622,7 @@ def main():
                                        + (" (one rank: --force-collectives rehearsal)" if world == 1 else "")),
                        "kernel": kernel_label,
                        "kernel_variant": args.variant, "integrator": args.integrator},
-            "roofline": {"bound": "valu_fp64" if prec == nb.FP64 else "valu_fp32", "achieved": round(ach, 3),
+            "roofline": {"bound": "valu_fp32" if prec == nb.FP32 else "valu_fp64", "achieved": round(ach, 3),
                          "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                          # PMC bytes (profiles/traffic.json holds them per STEP), per launch like `achieved`
                          "traffic": (round(traffic / launches) if traffic else None), "traffic_per_step": traffic,

@@ -58,6 +58,18 @@ typedef enum {
                                Systems of at most NBODY_MI355X_WAVE_MAX_BODIES bodies are
                                latency-bound and run the double kernels either way (faster there) */
 
+#define NBODY_MI355X_FP64_FAST 2 /* opt-in, never the default: FP64 with the correction series of r^-3
+                               cut after its linear term, y0^3 (1 + 3/2 e) instead of
+                               y0^3 (1 + 3/2 e + 15/8 e^2): 17 instead of 18 FP64 operations per pair,
+                               +5.7 % at N = 1M (3313 against 3129 Ginteractions/s, one lease).  The
+                               truncation is <= 15/8 e^2 <= 2.7e-14 relative per pair (e <= 2^-23:
+                               v_rsq_f64's seed), always towards a smaller r^-3: three to four orders
+                               inside north_star's 1e-10 after 100 steps, but outside the 1e-12 /
+                               1e-13 this library's FP64 path is tested to -- hence a tier of its
+                               own.  It changes the pair-symmetric kernels' equal-mass form with
+                               2048-body workgroup tiles (from 262 144 slots) and 512-body wave tiles
+                               (from 14 336 slots); every other kernel computes plain FP64. */
+
 /* Time integrator fused into the step's epilogue.
  * EULER: the reference's forward Euler, v' = v + dt a, r' = r + dt v (OLD v)
  *        (ref: particle_simulation.h:288-300) -- the parity path.
@@ -126,7 +138,7 @@ typedef struct {
   double eps2;            /* softening^2; 0 = reference semantics: pairs with
                              r^2 == 0 contribute nothing (ref:
                              particle_simulation.h:269)                        */
-  int32_t precision;      /* NBODY_MI355X_FP64 / _FP32                         */
+  int32_t precision;      /* NBODY_MI355X_FP64 / _FP32 / _FP64_FAST             */
   int32_t variant;        /* 0 = default kernel choice; >0 selects a specific
                              kernel build (tuning / A-B benchmarking);
                              NBODY_MI355X_VARIANT_SYM* = pair-symmetric kernels */
@@ -259,7 +271,7 @@ typedef struct {
   double stepsize;       /* ref: stepsize_                                     */
   double G;              /* 0 -> NBODY_MI355X_G_REFERENCE                      */
   double eps2;           /* 0 = reference semantics                            */
-  int32_t precision;     /* NBODY_MI355X_FP64 / _FP32                          */
+  int32_t precision;     /* NBODY_MI355X_FP64 / _FP32 / _FP64_FAST             */
   int32_t device;        /* HIP device ordinal                                 */
   int32_t host_is_float; /* 0: host records are double (ParticleSimulation<double,W>),
                             1: float (ParticleSimulation<float,W>)             */

@@ -652,7 +652,7 @@ int nbody_internal::check_step_args(const nbody_mi355x_step_args* a) {
     return NBODY_MI355X_ERR_INVALID;
   }
   if (!(a->eps2 >= 0.0)) { set_error("step: eps2 must be >= 0"); return NBODY_MI355X_ERR_INVALID; }
-  if (a->precision != NBODY_MI355X_FP64 && a->precision != NBODY_MI355X_FP32) {
+  if (a->precision != NBODY_MI355X_FP64 && a->precision != NBODY_MI355X_FP32 && a->precision != NBODY_MI355X_FP64_FAST) {
     set_error("step: unknown precision %d", a->precision);
     return NBODY_MI355X_ERR_INVALID;
   }

@@ -93,7 +93,7 @@ int free_all(nbody_mi355x_sim* s) {
 static int check_config(const nbody_mi355x_config* cfg) {
   if (cfg->num_particles <= 0) { set_error("create: num_particles must be > 0"); return NBODY_MI355X_ERR_INVALID; }
   if (!(cfg->eps2 >= 0.0)) { set_error("create: eps2 must be >= 0"); return NBODY_MI355X_ERR_INVALID; }
-  if (cfg->precision != NBODY_MI355X_FP64 && cfg->precision != NBODY_MI355X_FP32) {
+  if (cfg->precision != NBODY_MI355X_FP64 && cfg->precision != NBODY_MI355X_FP32 && cfg->precision != NBODY_MI355X_FP64_FAST) {
     set_error("create: unknown precision %d", cfg->precision);
     return NBODY_MI355X_ERR_INVALID;
   }

@@ -85,7 +85,7 @@ __device__ __forceinline__ void tile_phases(const P2<T>* xy, const P2<T>* zm, T 
     group_steps<IPT, SYM, MODE, T>(xy, zm, gb, lane, xi, yi, zi, mi, ax, ay, az, eps2, c15, c1875, inv_m_ref, 0, 8, &fx,
                                    &fy, &fz);
     if (SYM) {  // the sums are home: lane l holds body l of the group
-      if constexpr (MODE == kDeferred) {
+      if constexpr (MODE == kDeferred || MODE == kDeferredFast) {
         fx *= m_ref;
         fy *= m_ref;
         fz *= m_ref;
@@ -98,7 +98,7 @@ __device__ __forceinline__ void tile_phases(const P2<T>* xy, const P2<T>* zm, T 
   }
 }
 
-template <int IPT, typename T>
+template <int IPT, typename T, bool FAST = false>
 __global__ __launch_bounds__(256) void sym_tiles_kernel(const SymArgs a) {
   constexpr int B = 256 * IPT;
   constexpr int G = staged_groups<IPT>();  // groups per LDS fill
@@ -213,8 +213,10 @@ __global__ __launch_bounds__(256) void sym_tiles_kernel(const SymArgs a) {
   tile_phases<IPT, SYM_, MODE_, T>(xy, zm, fJ, lane, w, cg, xi, yi, zi, mi, ax, ay, az, eps2, c15, c1875, m_ref, inv_m_ref)
       if (sym) {
         if (kDouble) {
-          if (equal_mass) NBODY_TILE(true, kDeferred);
-          else if (row_uniform) NBODY_TILE(true, kRowUnit);
+          if (equal_mass) {
+            if constexpr (FAST) NBODY_TILE(true, kDeferredFast);
+            else NBODY_TILE(true, kDeferred);
+          } else if (row_uniform) NBODY_TILE(true, kRowUnit);
           else NBODY_TILE(true, kGeneral);
         } else {
           if (equal_mass) NBODY_TILE(true, kSameMass);
@@ -613,6 +615,12 @@ bool make_plan(const nbody_mi355x_step_args& a, Plan* p) {
 
 template <int IPT, typename T>
 hipError_t launch_wg_tiles(const SymArgs& sa, dim3 grid, hipStream_t stream) {
+  if constexpr (IPT == 8 && sizeof(T) == sizeof(double)) {  // the FAST tier: 2048-body blocks only (the large systems)
+    if (sa.fast) {
+      hipLaunchKernelGGL((sym_tiles_kernel<IPT, T, true>), grid, dim3(256), 0, stream, sa);
+      return hipGetLastError();
+    }
+  }
   hipLaunchKernelGGL((sym_tiles_kernel<IPT, T>), grid, dim3(256), 0, stream, sa);
   return hipGetLastError();
 }
@@ -780,6 +788,7 @@ int sym_step(const nbody_mi355x_step_args& a, hipStream_t stream) {
   sa.bshift = 0;
   while ((int64_t{1} << sa.bshift) < p.block) sa.bshift++;
   sa.trace = nullptr;
+  sa.fast = a.precision == NBODY_MI355X_FP64_FAST ? 1 : 0;
   sa.q = 0;  // (wave tiles: set per launch, set_octets)
   sa.q_magic = 0;
   sa.wstride = 4 * p.rchunks;

@@ -41,6 +41,7 @@ struct SymArgs {
   double* Cb;          // [nbs][wstride][3][64]: j-side sums of the SECOND part of a cut entry, by
                        // the wave that computed it (the first part goes to C like a whole entry)
   int wstride;         // waves per row in Cb's indexing (4 * chunks of the largest launch)
+  int fast;            // 1: NBODY_MI355X_FP64_FAST -- equal-mass tiles take kDeferredFast
   double eps2;
   // tuning only (NBODY_MI355X_SYMW_TRACE, nbody_symw.hip): per workgroup {start, end (100 MHz
   // clock), HW_ID, XCC_ID}; nullptr in every normal launch
@@ -93,6 +94,20 @@ __device__ __forceinline__ double pair_r3(double dx, double dy, double dz, doubl
   return __builtin_fma(we, p, w0);  // r^-3
 }
 __device__ __forceinline__ float pair_r3(float, float, float, float, float, float) { return 0.0f; }  // (double only)
+// The same with the series cut after the LINEAR term, y0^3 (1 + 3/2 e): one operation fewer
+// per pair (17 + rsq), truncation error 15/8 e^2 relative -- e <= 2^-23 for v_rsq_f64's seed
+// (tools/ubench_fp64.hip), i.e. <= 2.7e-14 per pair: three orders inside north_star's 1e-10,
+// outside this library's own 1e-12 asserts -- hence a precision tier of its own
+// (NBODY_MI355X_FP64_FAST), never the default.
+__device__ __forceinline__ double pair_r3_fast(double dx, double dy, double dz, double eps2, double c15) {
+  const double r2 = __builtin_fma(dz, dz, __builtin_fma(dy, dy, __builtin_fma(dx, dx, eps2)));
+  const double y0 = __builtin_amdgcn_rsq(r2);
+  const double u = y0 * y0;
+  const double e = __builtin_fma(-r2, u, 1.0);
+  const double w0 = y0 * u;
+  const double we = w0 * e;
+  return __builtin_fma(we, c15, w0);  // r^-3
+}
 template <bool WANT_J>
 __device__ __forceinline__ void pair_weights(double dx, double dy, double dz, double mj, double mi, double eps2,
                                              double c15, double c1875, double* si, double* sj) {
@@ -135,7 +150,8 @@ constexpr int kGrp = 72;
 //              alone can leave float's range) and one product serves both sides: 19.
 // kDeferred / kRowUnit round once more per sum than kGeneral (the final product with m_ref):
 // results agree to an ulp or two of each sum, not bit for bit.
-enum { kGeneral = 0, kDeferred = 1, kRowUnit = 2, kSameMass = 3 };
+//   kDeferredFast  (double, NBODY_MI355X_FP64_FAST) kDeferred with pair_r3_fast: 17 operations.
+enum { kGeneral = 0, kDeferred = 1, kRowUnit = 2, kSameMass = 3, kDeferredFast = 4 };
 
 // The FP32 walk with PACKED arithmetic: two of the lane's bodies per instruction.
 // Measured on gfx950 (tools/ubench_valu_rates.hip, ns per wave instruction per SIMD):
@@ -360,6 +376,8 @@ __device__ __forceinline__ void group_steps(const P2<T>* xy, const P2<T>* zm, in
         T si, sj = 0;
         if constexpr (MODE == kDeferred) {
           si = sj = pair_r3(dx, dy, dz, eps2, c15, c1875);
+        } else if constexpr (MODE == kDeferredFast) {
+          if constexpr (sizeof(T) == sizeof(double)) si = sj = pair_r3_fast(dx, dy, dz, eps2, c15);
         } else if constexpr (MODE == kRowUnit) {
           pair_weights<SYM>(dx, dy, dz, jzm.b, mi[k], eps2, c15, c1875, &si, &sj);
           si *= inv_m_ref;

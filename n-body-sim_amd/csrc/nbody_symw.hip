@@ -79,7 +79,7 @@ __device__ __forceinline__ void wave_origin(const double* px, const double* pm, 
   *scale = uniform(pow2_scale(ext));
 }
 
-template <int IPT, typename T>
+template <int IPT, typename T, bool FAST = false>
 __global__ __launch_bounds__(256) void sym_wave_kernel(const SymArgs a) {
   constexpr int B = 64 * IPT;
   constexpr bool kDouble = sizeof(T) == sizeof(double);
@@ -188,7 +188,8 @@ __global__ __launch_bounds__(256) void sym_wave_kernel(const SymArgs a) {
     if (d != 0) {
       if (kDouble) {
         if (equal_mass) {
-          NBODY_GROUP(true, kDeferred);
+          if constexpr (FAST) NBODY_GROUP(true, kDeferredFast);  // (NBODY_MI355X_FP64_FAST, 512-body blocks)
+          else NBODY_GROUP(true, kDeferred);
           fx *= m_ref;
           fy *= m_ref;
           fz *= m_ref;
@@ -269,6 +270,12 @@ __global__ __launch_bounds__(256) void sym_wave_kernel(const SymArgs a) {
 
 template <int IPT, typename T>
 hipError_t launch_one(const SymArgs& sa, dim3 grid, hipStream_t stream) {
+  if constexpr (IPT == 8 && sizeof(T) == sizeof(double)) {  // the FAST tier: 512-body blocks only
+    if (sa.fast) {
+      hipLaunchKernelGGL((sym_wave_kernel<IPT, T, true>), grid, dim3(256), 0, stream, sa);
+      return hipGetLastError();
+    }
+  }
   hipLaunchKernelGGL((sym_wave_kernel<IPT, T>), grid, dim3(256), 0, stream, sa);
   return hipGetLastError();
 }

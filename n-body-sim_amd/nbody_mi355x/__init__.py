@@ -24,7 +24,7 @@ LIB_PATH = Path(os.environ["NBODY_MI355X_LIB"]) if os.environ.get("NBODY_MI355X_
 
 TILE = 256
 G_REFERENCE = 6.7430e-11  # reference: particle_simulation.h:713
-FP64, FP32 = 0, 1
+FP64, FP32, FP64_FAST = 0, 1, 2   # FP64_FAST: opt-in tier, include/nbody_mi355x.h
 EULER, KICK_DRIFT, KDK, KDK_CONTINUE = 0, 1, 2, 3   # KDK_CONTINUE: level 1 (StepArgs) only
 
 OK = 0

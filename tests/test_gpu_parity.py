@@ -235,6 +235,59 @@ def test_full_size_sampled_rows_and_momentum(n):
     assert np.linalg.norm(f) <= 1e-12 * scale
 
 
+# ----------------------------------------------------------------- the opt-in FP64_FAST tier
+@pytest.mark.parametrize("name", ["g1_earth_moon", "g2_earth_7moons", "g3_saturn_ring_500", "g4_plummer_1024",
+                                  "g4_plummer_4096", "g7_edge_cases", "g8_si_cloud_512"])
+def test_fp64_fast_tier_against_reference_golden(name):
+    """NBODY_MI355X_FP64_FAST at north_star's bar on every golden fixture (these sizes run kernels
+    the tier does not change: the request must simply be honoured everywhere)."""
+    g = load_golden(name)
+    _, out = gpu_simulate(g["particles"], g["mass"], int(g["big_steps"]), int(g["substeps"]), float(g["dt"]),
+                          precision=nb.FP64_FAST)
+    assert rel_pos_err(out[..., 0:3], ref_out(g)[..., 0:3]) <= FP64_TOL
+
+
+def test_fp64_fast_tier_65536_full_trajectory_and_energy():
+    """The tier where it changes the arithmetic (512-body wave tiles): Plummer N = 65 536, 100
+    small steps against the oracle's AVX2 path -- r^-3 truncated after the linear term is
+    <= 2.7e-14 per pair, positions stay three orders inside north_star's 1e-10, the energy drift
+    within 1 % of the reference's; and it is NOT the default kernel (different bits)."""
+    n = 65536
+    p, m = nb.ic_plummer(n, 42)
+    _, ref = ol.simulate(p, m, 1, 100, 1e-3, threads=16, kind="avx2")
+    _, out = gpu_simulate(p, m, 1, 100, 1e-3, precision=nb.FP64_FAST)
+    _, std = gpu_simulate(p, m, 1, 100, 1e-3)
+    err = rel_pos_err(out[0, :, :3], ref[0, :, :3])
+    assert err <= FP64_TOL and err <= 1e-11
+    assert not np.array_equal(out, std)
+    assert vec_rel(out[0, :, 6:9], ref[0, :, 6:9]) <= 1e-11
+    e0 = sum(ol.energy(p, m, threads=16))
+    drift_ref = sum(ol.energy(ref[0], m, threads=16)) - e0
+    drift_gpu = sum(ol.energy(out[0], m, threads=16)) - e0
+    assert abs(drift_gpu / drift_ref - 1) <= 0.01
+
+
+@pytest.mark.parametrize("n", [262144, 1048576])
+def test_fp64_fast_tier_sampled_rows_at_bench_sizes(n):
+    """... and with the 2048-body workgroup tiles (the headline's kernel family): sampled rows
+    against the oracle, momentum, and how far the tier is from the default path."""
+    p, m = nb.ic_plummer(n, 42)
+    outs = {}
+    for prec in (nb.FP64, nb.FP64_FAST):
+        with nb.Simulation(n, 1e-3, precision=prec) as sim:
+            sim.upload(p, m)
+            outs[prec] = sim.run(1, snapshot=True)
+    rows = np.random.default_rng(0).choice(n, 1024, replace=False)
+    acc = ol.accel_rows(p, m, rows, threads=16)
+    fast, std = outs[nb.FP64_FAST], outs[nb.FP64]
+    assert vec_rel(fast[rows, 6:9], acc) <= 1e-11
+    assert vec_rel(std[rows, 6:9], acc) <= 1e-12
+    d = vec_rel(fast[:, 6:9], std[:, 6:9])
+    assert 0 < d <= 1e-11, d                       # another kernel, the same forces to 1e-11
+    f = (m[:, None] * fast[:, 6:9]).sum(0)
+    assert np.linalg.norm(f) <= 1e-12 * (m * np.linalg.norm(fast[:, 6:9], axis=1)).sum()
+
+
 def test_fp32_plummer_1m_sampled_rows_and_momentum():
     """The workload of the FP32 headline figure (Plummer N = 1 048 576, float pair arithmetic):
     exact accelerations of 1024 sampled rows from the oracle, within 1e-4 of the largest |a| --
