@@ -237,7 +237,8 @@ int nbody_mi355x_step_workspace_min_bytes(const nbody_mi355x_step_args* args, in
  * workspace exceeds the array (about 170 000 bodies on one slab) are rejected with
  * NBODY_MI355X_ERR_INVALID and a text that names the size needed; so are one-sided variants
  * (they need no scratch: call nbody_mi355x_step_f64) and layouts the pair-symmetric kernels
- * do not apply to (fewer than two 256-slot blocks).  Results are bit-identical to
+ * do not apply to (fewer than two blocks of the variant's size; with variant 0 the smallest
+ * layout is one 256-slot slab, taken as 128-slot wave-tile blocks).  Results are bit-identical to
  * nbody_mi355x_step_f64 given a workspace of NBODY_MI355X_STATIC_SCRATCH_BYTES.
  * All calls on one GPU share that GPU's array: calls that overlap on one GPU (two streams,
  * two host threads) race -- serialise them.  Nothing in the array needs clearing between

@@ -397,7 +397,9 @@ int env_int(const char* name) {  // tuning experiments only
 // (1024 SIMDs x several waves), fewer parts where there are slots enough
 int parts_for(int64_t slots) {
   if (const int v = env_int("NBODY_MI355X_SYM_PARTS"); v == 4 || v == 8 || v == 16) return v;  // (A/B tests)
-  return slots <= 32768 ? 16 : (slots <= 131072 ? 8 : 4);
+  // (beyond ~32 768 slots the launch is bandwidth-bound whatever the parts: 65 536 bodies, 116 MB
+  // of partials: 20.0 us with 4 parts, 22.1 with 8)
+  return slots <= 32768 ? 16 : 4;
 }
 void launch_finish(int parts, unsigned groups, hipStream_t stream, const SymArgs& sa, const nbody_mi355x_step_args& a) {
   if (parts == 16) hipLaunchKernelGGL(sym_finish_kernel<16>, dim3(groups), dim3(64, 16), 0, stream, sa, a);

@@ -83,6 +83,98 @@ def test_static_entry_point_matches_the_allocating_one(precision):
         assert np.abs(snap[:, 6:9] - orc[0, :, 6:9]).max() <= tol_a * scale
 
 
+def _call(entry, a, ws, stream):
+    L = nb.lib()
+    if entry == "static":
+        a.workspace, a.workspace_bytes = None, 0
+        nb.check(L.nbody_mi355x_step_f64_static(C.byref(a), stream))
+    else:
+        a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel() * 8
+        nb.check(L.nbody_mi355x_step_f64(C.byref(a), stream))
+
+
+def test_static_entry_point_workgroup_tiles_in_several_batches():
+    """The other kernel family through the shared array: workgroup tiles with 256-body
+    blocks (variant SYM1) on a system whose block distances do not fit the 128 MiB at once -- the
+    distances are walked in batches that reuse the C rows, the accumulator lives in the array
+    too.  Bit for bit against the allocating entry point with a workspace of the same size."""
+    import torch
+    dev = torch.device("cuda", 0)
+    n = 100000
+    p, m = nb.ic_plummer(n, 9)
+    S = nb.round_up(n, 2048)
+    ws = torch.full((nb.STATIC_SCRATCH_BYTES // 8,), float("nan"), dtype=torch.float64, device=dev)
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    out = {}
+    for entry in ("workspace", "static"):
+        pos, vel, mass = _slab(p, m, S, dev)
+        nxt = torch.zeros_like(pos)
+        snap = torch.full((n, 9), np.nan, dtype=torch.float64, device=dev)
+        a = nb.StepArgs()
+        a.pos_cur, a.pos_next, a.mass, a.vel, a.snapshot = pos.data_ptr(), nxt.data_ptr(), mass.data_ptr(), vel.data_ptr(), snap.data_ptr()
+        a.shard_slots, a.num_shards, a.own_shard, a.own_count = S, 1, 0, n
+        a.j0_begin, a.j0_end = 0, n
+        a.dt, a.G, a.eps2, a.precision, a.variant = 1e-3, nb.G_REFERENCE, 0.0, nb.FP64, nb.VARIANT_SYM1
+        if entry == "workspace":
+            a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel() * 8
+            launches = C.c_int32(0)
+            nb.check(nb.lib().nbody_mi355x_step_tile_launches(C.byref(a), C.byref(launches)))
+            assert launches.value >= 3, "the case is meant to need several distance batches"
+        _call(entry, a, ws, stream)
+        torch.cuda.synchronize(dev)
+        out[entry] = (nxt.cpu().numpy(), vel.cpu().numpy(), snap.cpu().numpy())
+    for r, g in zip(out["workspace"], out["static"]):
+        assert np.array_equal(r, g)
+    rows = np.random.default_rng(0).choice(n, 512, replace=False)
+    acc = ol.accel_rows(p, m, rows, threads=16)
+    got = out["static"][2][rows, 6:9]
+    assert (np.linalg.norm(got - acc, axis=1) / np.linalg.norm(acc, axis=1)).max() <= 1e-12
+
+
+@pytest.mark.parametrize("variant", [nb.VARIANT_SYM, nb.VARIANT_SYM2])
+def test_static_entry_point_two_slabs_phase_1_then_2(variant):
+    """Several slabs through the shared array: phase 1 leaves the diagonal tiles' sums
+    in the array's R rows for the phase 2 call that follows (with acc_out: this rank's partial
+    sums for every slot).  Both "ranks" of a two-slab layout in turn, on one GPU, bit for bit
+    against the allocating entry point; the two ranks' partial sums added = the oracle's sums."""
+    import torch
+    dev = torch.device("cuda", 0)
+    n, P = 24000, 2
+    p, m = nb.ic_plummer(n, 77)
+    half = n // P
+    S = nb.round_up(half, 1024)
+    pos = np.zeros((P, 3, S)); mass = np.zeros((P, S))
+    for r in range(P):
+        pos[r, :, :half] = p[r * half:(r + 1) * half, :3].T
+        mass[r, :half] = m[r * half:(r + 1) * half]
+    pos_d, mass_d = torch.from_numpy(pos).to(dev), torch.from_numpy(mass).to(dev)
+    nxt = torch.zeros_like(pos_d)
+    vel = torch.zeros((3, S), dtype=torch.float64, device=dev)
+    ws = torch.full((nb.STATIC_SCRATCH_BYTES // 8,), float("nan"), dtype=torch.float64, device=dev)
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    sums = {}
+    for entry in ("workspace", "static"):
+        total = torch.zeros((P, 3, S), dtype=torch.float64, device=dev)
+        for r in range(P):
+            acc_all = torch.full((P, 3, S), float("nan"), dtype=torch.float64, device=dev)
+            for phase in (1, 2):
+                a = nb.StepArgs()
+                a.pos_cur, a.pos_next, a.mass, a.vel = pos_d.data_ptr(), nxt.data_ptr(), mass_d.data_ptr(), vel.data_ptr()
+                a.acc_out = acc_all.data_ptr() if phase == 2 else None
+                a.shard_slots, a.num_shards, a.own_shard, a.own_count = S, P, r, half
+                a.dt, a.G, a.eps2, a.precision, a.variant, a.phase = 1e-3, nb.G_REFERENCE, 0.0, nb.FP64, variant, phase
+                _call(entry, a, ws, stream)
+            torch.cuda.synchronize(dev)
+            sums[(entry, r)] = acc_all.cpu().numpy()
+            total += acc_all
+        sums[entry] = total.cpu().numpy()
+    for r in range(P):
+        assert np.array_equal(sums[("workspace", r)], sums[("static", r)])
+    got = np.concatenate([sums["static"][r, :, :half].T for r in range(P)]) * nb.G_REFERENCE
+    acc = ol.accel_rows(p, m, np.arange(n), threads=16)
+    assert (np.linalg.norm(got - acc, axis=1) / np.linalg.norm(acc, axis=1)).max() <= 1e-12
+
+
 def test_static_entry_point_rejects_what_does_not_fit():
     import torch
     dev = torch.device("cuda", 0)
