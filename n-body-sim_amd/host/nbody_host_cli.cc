@@ -8,7 +8,7 @@
 //       write the initial conditions of a reference scene (earth_moon | earth_7moons |
 //       slingshoot | saturn_ring) as  int64 n, double[n][6] {r,v}, double[n] m
 //   nbody_host_cli run    PATH IN.bin BIG SUB DT THREADS OUT.bin
-//       PATH = cpu | avx2 | avx512 | mi355x | mi355x-fp32 | mi355x-shardsK | cpu-f32 | avx512-f32 | mi355x-f32host
+//       PATH = cpu | avx2 | avx512 | mi355x | mi355x-fp32 | mi355x-fast | mi355x-shardsK | cpu-f32 | avx512-f32 | mi355x-f32host
 //       read IN.bin (format above), simulate BIG big steps of SUB small steps, write
 //       OutPutParticle rows double[(BIG+1)][n][11] {r,v,a,m,t} (float runs are widened); one JSON
 //       line on stdout with the host's wall clock of every big step
@@ -128,6 +128,7 @@ std::string Simulate(ParticleSimulation<T, W>& sim, const std::string& path) {
   if (path == "avx512" || path == "avx512-f32") return sim.SimulateAVX512() ? "ok" : "no AVX-512F on this CPU";
   if (path == "mi355x" || path == "mi355x-f32host") return sim.SimulateMI355X();
   if (path == "mi355x-fp32") return sim.SimulateMI355X(0, true);
+  if (path == "mi355x-fast") { sim.SetMI355XPrecision(NBODY_MI355X_FP64_FAST); return sim.SimulateMI355X(); }
   if (path == "mi355x-kdk") return sim.SimulateMI355X(0, false, 0, NBODY_MI355X_KDK);
   if (path.rfind("mi355x-shards", 0) == 0) {  // mi355x-shardsK: K shards, round-robin over the visible GPUs
     const int k = std::atoi(path.c_str() + 13);

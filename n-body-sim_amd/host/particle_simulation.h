@@ -376,7 +376,7 @@ class ParticleSimulation {
     cfg.stepsize = static_cast<double>(stepsize_);
     cfg.G = static_cast<double>(G_);
     cfg.eps2 = static_cast<double>(softening_squared);
-    cfg.precision = fp32_forces ? NBODY_MI355X_FP32 : NBODY_MI355X_FP64;
+    cfg.precision = mi355x_precision_ >= 0 ? mi355x_precision_ : (fp32_forces ? NBODY_MI355X_FP32 : NBODY_MI355X_FP64);
     cfg.device = devices.empty() ? 0 : devices[0];
     cfg.host_is_float = std::is_same<float_t, float>::value ? 1 : 0;
     cfg.integrator = integrator;
@@ -510,6 +510,9 @@ class ParticleSimulation {
   const float_t* Masses() const { return mass_.data(); }
   int NumParticles() const { return num_particles_; }
   void SetQuiet(bool quiet) { quiet_ = quiet; }
+  // The arithmetic tier SimulateMI355X() asks the library for, overriding its fp32_forces flag:
+  // NBODY_MI355X_FP64 (the parity path), _FP32 or _FP64_FAST (include/nbody_mi355x.h); -1: the flag decides.
+  void SetMI355XPrecision(int tier) { mi355x_precision_ = tier; }
 
  private:
   static constexpr float_t G_ = 6.7430e-11;  // ref: particle_simulation.h:713 (sic)
@@ -774,5 +777,6 @@ class ParticleSimulation {
   std::vector<double> execution_time_;
   int64_t total_execution_time_ = 0;
   bool quiet_ = false;
+  int mi355x_precision_ = -1;
   nbody_host_detail::WorkerPool pool_;
 };

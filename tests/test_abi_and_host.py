@@ -123,6 +123,8 @@ def test_python_constants_mirror_the_header():
     assert [int(defs[k]) for k in ("EULER", "KICK_DRIFT", "KDK", "KDK_CONTINUE")] == [nb.EULER, nb.KICK_DRIFT, nb.KDK, nb.KDK_CONTINUE]
     assert [int(defs[f"VARIANT_SYMW{k}"]) for k in (1, 2, 4, 8)] == [nb.VARIANT_SYMW1, nb.VARIANT_SYMW2, nb.VARIANT_SYMW4, nb.VARIANT_SYMW8]
     assert int(defs["STATIC_SCRATCH_BYTES"]) == nb.STATIC_SCRATCH_BYTES
+    assert [int(defs[k]) for k in ("FP64", "FP32", "FP64_FAST")] == [nb.FP64, nb.FP32, nb.FP64_FAST]
+    assert [int(defs[f"EXCHANGE_{k}"]) for k in ("NONE", "PEER_COPIES", "RCCL")] == [nb.EXCHANGE_NONE, nb.EXCHANGE_PEER_COPIES, nb.EXCHANGE_RCCL]
 
 
 def test_step_variant_reports_the_kernel_choice_without_a_gpu():
@@ -147,7 +149,9 @@ def test_step_variant_reports_the_kernel_choice_without_a_gpu():
     big = 1 << 40
     assert variant_of(500) == nb.VARIANT_WAVE and variant_of(nb.WAVE_MAX_BODIES, big) == nb.VARIANT_WAVE
     assert variant_of(100000) in (1, 2) and variant_of(1048576) == 2          # no workspace: one-sided
-    assert variant_of(8192, big) == nb.VARIANT_SYMW4 and variant_of(16384, big) == nb.VARIANT_SYMW4
+    assert variant_of(8192, big) == nb.VARIANT_SYMW4 and variant_of(12288, big) == nb.VARIANT_SYMW4
+    assert variant_of(16384, big) == nb.VARIANT_SYMW8          # 512-body blocks from 14 336 slots (round 3's sweep)
+    assert variant_of(1048576, big, precision=nb.FP64_FAST) == nb.VARIANT_SYM8   # the tier changes the arithmetic, not the plan
     assert variant_of(65536, big) == nb.VARIANT_SYMW8 and variant_of(1048576, big) == nb.VARIANT_SYM8
     assert variant_of(65536, big, precision=nb.FP32) == nb.VARIANT_SYMW8 and variant_of(1048576, big, precision=nb.FP32) == nb.VARIANT_SYM8
     assert variant_of(65536, 4096) in (1, 2)                                  # workspace below the minimum
