@@ -315,6 +315,8 @@ int nbody_mi355x_upload(nbody_mi355x_sim* sim, const void* particles, const void
  * DeviceOutputParticle<T>[N] = {r, v, a*G} there (host memory).  Blocks until
  * the big step is complete (the reference's per-big-step timing needs that). */
 int nbody_mi355x_run(nbody_mi355x_sim* sim, int64_t substeps, void* snapshot_out);
+/* (A run that fails part-way -- ERR_LAUNCH and the like -- leaves the state undefined, on a
+ * multi-device handle possibly different from shard to shard: upload or generate again.) */
 /* The same in two halves, so that the host can unpack / write big step k's
  * snapshot while big step k+1 runs (the reference copies every
  * snapshot at the very end, .cu:198-211): run_async enqueues the big step and the
