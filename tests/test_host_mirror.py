@@ -236,6 +236,14 @@ def test_cli_bench_mi355x():
 
 
 @pytest.mark.gpu
+def test_cli_bench_mi355x_fast_tier_through_the_host_mirror():
+    """SetMI355XPrecision(NBODY_MI355X_FP64_FAST) + SimulateMI355X(): the opt-in tier from C++."""
+    line, status = _cli_bench("plummer", 65536, "mi355x-fast", 3, 5)
+    assert "Simulation on MI355X succesfull." in status
+    assert line["Ginteractions_per_s"] > 500
+
+
+@pytest.mark.gpu
 def test_reference_saturn_ring_main_on_the_gpu(tmp_path):
     """The reference's OWN saturn_ring.cc with the one `Simulate` line swapped for
     SimulateMI355X() (built in the build container by `make -C oracle ref-scenes` against this
