@@ -234,7 +234,8 @@ int nbody_mi355x_step_workspace_min_bytes(const nbody_mi355x_step_args* args, in
  * of the library's code object -- NBODY_MI355X_STATIC_SCRATCH_BYTES on every GPU the library
  * runs on, held until the process ends.  args->workspace / workspace_bytes are ignored.
  * It calls no hipMalloc / hipFree or any other allocating routine.  Layouts whose MINIMUM
- * workspace exceeds the array (about 170 000 bodies on one slab) are rejected with
+ * workspace exceeds the array (one slab: every size up to 124 928 bodies fits,
+ * some layouts up to about 170 000 -- nbody_mi355x_step_workspace_min_bytes tells) are rejected with
  * NBODY_MI355X_ERR_INVALID and a text that names the size needed; so are one-sided variants
  * (they need no scratch: call nbody_mi355x_step_f64) and layouts the pair-symmetric kernels
  * do not apply to (fewer than two blocks of the variant's size; with variant 0 the smallest
