@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void sym_wave_kernel(const SymArgs a) {
   T c15 = static_cast<T>(1.5), c1875 = static_cast<T>(1.875);
   asm volatile("" : "+v"(c15), "+v"(c1875));
   if (a.trace != nullptr && tid == 0) {  // (tuning runs only: where and when this workgroup ran)
-    unsigned long long* t = a.trace + 4 * (static_cast<size_t>(c) * gridDim.x + il);
+    unsigned long long* t = a.trace + 12 * (static_cast<size_t>(c) * gridDim.x + il);
     t[0] = wall_clock64();
     t[2] = __builtin_amdgcn_s_getreg((4) | (31 << 11));   // HW_REG_HW_ID
     t[3] = __builtin_amdgcn_s_getreg((20) | (31 << 11));  // HW_REG_XCC_ID
@@ -151,6 +151,9 @@ __global__ __launch_bounds__(256) void sym_wave_kernel(const SymArgs a) {
 
   P2<T>* wxy = xy[w];
   P2<T>* wzm = zm[w];
+  // (tuning runs only: where wave 0's time goes)
+  const bool timed = a.trace != nullptr;
+  unsigned long long t_loop = timed ? wall_clock64() : 0, t_stage = 0, t_walk = 0, t_store = 0, t_done = 0, n_done = 0, t0 = t_loop;
   for (int o = o_begin; o < o_end;) {
     const int e = o >> 3, k0 = o & 7;                        // entry, first octet of it taken here
     const int k1 = o_end - 8 * e < 8 ? o_end - 8 * e : 8;    // one past the last
@@ -180,6 +183,7 @@ __global__ __launch_bounds__(256) void sym_wave_kernel(const SymArgs a) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (timed) { const unsigned long long t = wall_clock64(); t_stage += t - t0; t0 = t; }
 
     T fx = 0, fy = 0, fz = 0;
 #define NBODY_GROUP(SYM_, MODE_)                                                                                  \
@@ -206,6 +210,7 @@ __global__ __launch_bounds__(256) void sym_wave_kernel(const SymArgs a) {
       // (a whole walk, or one that ends with the entry: its own body l).  A part that BEGINS
       // the entry goes where a whole entry's sums go, C[d][I][group]; a part that begins
       // inside it is the second part of a cut entry: Cb[I][this wave]
+      if (timed) { const unsigned long long t = wall_clock64() + (fx == static_cast<T>(12345.5) ? 1 : 0); t_walk += t - t0; t0 = t; }
       const int body = (lane + 8 * k1) & 63;
       double* out = k0 == 0 ? a.C + static_cast<int64_t>(d - a.c_base) * 3 * S + static_cast<int64_t>(il) * B + g * 64
                             : a.Cb + (static_cast<int64_t>(il) * a.wstride + wr) * 192;
@@ -226,7 +231,9 @@ __global__ __launch_bounds__(256) void sym_wave_kernel(const SymArgs a) {
     }
 #undef NBODY_GROUP
     __builtin_amdgcn_wave_barrier();
+    if (timed) { const unsigned long long t = wall_clock64(); (d != 0 ? t_store : t_walk) += t - t0; t0 = t; n_done++; }
   }
+  if (timed) t_done = wall_clock64();
 
   // the four waves' i-side sums, added in wave order
   if (w > 0) {
@@ -265,7 +272,16 @@ __global__ __launch_bounds__(256) void sym_wave_kernel(const SymArgs a) {
       Rs[2 * S + idx] = z;
     }
   }
-  if (a.trace != nullptr && tid == 0) a.trace[4 * (static_cast<size_t>(c) * gridDim.x + il) + 1] = wall_clock64();
+  if (a.trace != nullptr && tid == 0) {
+    unsigned long long* t = a.trace + 12 * (static_cast<size_t>(c) * gridDim.x + il);
+    t[1] = wall_clock64();
+    t[4] = t_loop;   // the row is in registers, the list begins
+    t[5] = t_stage;  // summed over wave 0's entries: from the entry's start to its bodies staged in LDS
+    t[6] = t_walk;   //   ... the walk
+    t[7] = t_store;  //   ... the j-side sums stored
+    t[8] = t_done;   // the list is done: what follows is the i-side sums through LDS and the R store
+    t[9] = n_done;   // entries (or parts) wave 0 walked
+  }
 }
 
 template <int IPT, typename T>
@@ -284,7 +300,7 @@ hipError_t launch_one(const SymArgs& sa, dim3 grid, hipStream_t stream) {
 
 // NBODY_MI355X_SYMW_TRACE=FILE (tuning only): every wave-tile launch is followed by a
 // synchronisation and appends one line per workgroup to FILE:
-//   launch  row  chunk  start  end (100 MHz ticks)  HW_ID  XCC_ID
+//   launch  row  chunk  start  end (100 MHz ticks)  HW_ID  XCC_ID  list-begins  sum(stage)  sum(walk)  sum(store)  list-done  entries
 // -- where the dispatcher put each workgroup and when it ran.  Allocates, blocks the host: never
 // set it in a measured run.
 hipError_t launch_wave_tiles_plain(int ipt, bool fp32, const SymArgs& sa, dim3 grid, hipStream_t stream);
@@ -295,17 +311,18 @@ hipError_t launch_wave_tiles(int ipt, bool fp32, const SymArgs& sa_in, dim3 grid
   if (path == nullptr || path[0] == 0) return launch_wave_tiles_plain(ipt, fp32, sa, grid, stream);
   static int launch_no = 0;
   const size_t count = static_cast<size_t>(grid.x) * grid.y;
-  hipError_t e = hipMalloc(reinterpret_cast<void**>(&sa.trace), count * 4 * sizeof(unsigned long long));
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(&sa.trace), count * 12 * sizeof(unsigned long long));
   if (e != hipSuccess) return e;
   e = launch_wave_tiles_plain(ipt, fp32, sa, grid, stream);
   if (e == hipSuccess) e = hipStreamSynchronize(stream);
   if (e == hipSuccess) {
-    std::vector<unsigned long long> h(count * 4);
+    std::vector<unsigned long long> h(count * 12);
     e = hipMemcpy(h.data(), sa.trace, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
     if (FILE* f = e == hipSuccess ? fopen(path, "a") : nullptr) {
       for (size_t k = 0; k < count; k++)
-        fprintf(f, "%d %zu %zu %llu %llu %llu %llu\n", launch_no, k % grid.x, k / grid.x, h[4 * k], h[4 * k + 1], h[4 * k + 2],
-                h[4 * k + 3]);
+        fprintf(f, "%d %zu %zu %llu %llu %llu %llu %llu %llu %llu %llu %llu %llu\n", launch_no, k % grid.x, k / grid.x, h[12 * k],
+                h[12 * k + 1], h[12 * k + 2], h[12 * k + 3], h[12 * k + 4], h[12 * k + 5], h[12 * k + 6], h[12 * k + 7],
+                h[12 * k + 8], h[12 * k + 9]);
       fclose(f);
     }
   }

@@ -9,12 +9,13 @@ import sys
 rows = collections.defaultdict(list)
 for ln in open(sys.argv[1]):
     f = ln.split()
-    if len(f) != 7:
+    if len(f) not in (7, 13):
         continue
-    launch, row, chunk, t0, t1, hw, xcc = (int(x) for x in f)
+    launch, row, chunk, t0, t1, hw, xcc = (int(x) for x in f[:7])
+    extra = [int(x) for x in f[7:]]
     # gfx9 HW_ID: wave 3:0, simd 5:4, pipe 7:6, cu 11:8, sh 12, se 15:13
     cu = (xcc & 0xf, (hw >> 13) & 7, (hw >> 12) & 1, (hw >> 8) & 0xf)
-    rows[launch].append((row, chunk, t0, t1, cu))
+    rows[launch].append((row, chunk, t0, t1, cu, extra))
 only = int(sys.argv[2]) if len(sys.argv) > 2 else None
 for launch, ws in sorted(rows.items()):
     if only is not None and launch != only:
@@ -36,3 +37,10 @@ for launch, ws in sorted(rows.items()):
           f"ends: first {ends[0]:.1f}, median {ends[len(ends) // 2]:.1f}, last {ends[-1]:.1f} us")
     xcd = collections.Counter(w[4][0] for w in ws)
     print("   workgroups per XCD: " + " ".join(f"{k}:{v}" for k, v in sorted(xcd.items())))
+    ex = [w for w in ws if w[5] and w[5][5] > 0]
+    if ex:   # where wave 0's time goes (microseconds, medians over the workgroups)
+        med = lambda v: sorted(v)[len(v) // 2] / 100.0
+        print(f"   wave 0: prologue (row in registers) {med([w[5][0] - w[2] for w in ex]):.2f} us; per entry: staged after "
+              f"{med([w[5][1] / w[5][5] for w in ex]):.2f}, walk {med([w[5][2] / w[5][5] for w in ex]):.2f}, j sums stored "
+              f"{med([w[5][3] / w[5][5] for w in ex]):.2f} us ({med([100.0 * w[5][5] for w in ex]):.0f} entries or parts); "
+              f"epilogue (i sums through LDS, R row) {med([w[3] - w[5][4] for w in ex]):.2f} us")

@@ -1,15 +1,20 @@
 #!/bin/bash
-# tools/diag_mid.sh -- per-kernel times (rocprofv3 kernel trace) of a few mid-size launch shapes
+# tools/diag_mid.sh [sizes] -- where the workgroups of the wave-tile launches ran and where a wave's
+# time goes (NBODY_MI355X_SYMW_TRACE; tuning only: allocates, blocks, a few steps per size)
 set -u
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-cd /tmp && export TMPDIR=/tmp
-OUT=$R/gpurun_out/r3_g
-rm -rf $OUT; mkdir -p $OUT
-for case in "8192 24 8" "8192 24 16" "8192 28 16" "16384 24 8" "16384 24 12" "16384 24 33" "16384 28 16" "16384 28 8" "32768 28 16"; do
-  set -- $case
-  export NBODY_MI355X_SYMW_CHUNKS=$3
-  tag=n$1_v$2_c$3
-  timeout -s KILL 120 rocprofv3 --kernel-trace --output-format csv -d $OUT/$tag -- python3 $R/tools/mid_case.py $1 $2 > $OUT/$tag.log 2>&1 || exit 1
-  echo "== $tag: $(grep us/step $OUT/$tag.log)"
-  python3 $R/tools/trace_gaps.py $OUT/$tag 100
-done
+SIZES=${1:-8192,16384,32768,65536}
+cd $R
+rm -f gpurun_out/wg_trace.txt
+NBODY_MI355X_SYMW_TRACE=$R/gpurun_out/wg_trace.txt SIZES=$SIZES timeout -k 10 200 python3 - <<'PY'
+import os, sys
+sys.path.insert(0, 'n-body-sim_amd')
+import nbody_mi355x as nb
+for n in [int(x) for x in os.environ["SIZES"].split(",")]:
+    p, m = nb.ic_plummer(n, 42)
+    with nb.Simulation(n, 1e-3) as sim:
+        sim.upload(p, m)
+        sim.run(30, snapshot=False)
+    print("traced", n, flush=True)
+PY
+python3 tools/analyze_wg_trace.py gpurun_out/wg_trace.txt | awk '/^launch/ {n++} { if ((n % 30) == 0 || (n % 30) == 29) print }'
