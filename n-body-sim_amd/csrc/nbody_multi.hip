@@ -531,6 +531,10 @@ bool rccl_self_check(MultiSim& m, char* why, size_t why_len) {
     snprintf(why, why_len, "self-check: ncclReduceScatter and the peer copies disagree");
     return false;
   }
+  if (const char* inject = getenv("NBODY_MI355X_MULTI_SELFCHECK_FAIL"); inject && atoi(inject) != 0) {
+    snprintf(why, why_len, "self-check: failure injected by NBODY_MI355X_MULTI_SELFCHECK_FAIL (tests)");
+    return false;  // (exercises the fall-back: communicators destroyed, peer copies, the reason reported)
+  }
   // and against the closed form (both could be wrong together): sum over ranks of the pattern
   for (int r = 0; r < P; r++)
     for (int64_t i = 0; i < len; i++) {

@@ -99,6 +99,45 @@ def test_multi_errors():
         assert sim.run(2).shape == (100, 9)
 
 
+def _rccl_fallback_main(q):
+    """Own process: the communicator is built, its self-check is made to fail (test hook), and the
+    handle must fall back to the peer copies, say why, and still compute the right thing."""
+    import os
+    import sys
+    from pathlib import Path
+    repo = Path(__file__).resolve().parent.parent
+    sys.path.insert(0, str(repo / "n-body-sim_amd"))
+    os.environ["NBODY_MI355X_MULTI_FORCE"] = "1"
+    os.environ["NBODY_MI355X_MULTI_RCCL"] = "1"
+    os.environ["NBODY_MI355X_MULTI_SELFCHECK_FAIL"] = "1"
+    import torch  # noqa: F401
+    import nbody_mi355x as nb
+    n = 20000
+    p, m = nb.ic_plummer(n, 13)
+    with nb.Simulation(n, 1e-3, devices=[0]) as sim:
+        text = nb.last_error()
+        backend = sim.exchange_backend()
+        sim.upload(p, m)
+        out = sim.run(3, snapshot=True)
+    q.put((text, backend, out))
+
+
+def test_rccl_self_check_failure_falls_back_to_peer_copies():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    pr = ctx.Process(target=_rccl_fallback_main, args=(q,))
+    pr.start()
+    text, backend, out = q.get(timeout=200)
+    pr.join(timeout=60)
+    assert pr.exitcode == 0
+    assert backend == nb.EXCHANGE_PEER_COPIES
+    assert "self-check" in text and "using peer copies" in text, text
+    p, m = nb.ic_plummer(20000, 13)
+    _, ref = ol.simulate(p, m, 1, 3, 1e-3, threads=16)
+    assert rel_pos_err(out[:, :3], ref[0, :, :3]) <= 1e-13
+
+
 def _rccl_one_rank_main(n, q):
     """Own process (the two environment switches are read at create): one shard through the
     multi-shard code with its exchanges done by RCCL -- ncclCommInitAll over one device,
