@@ -175,6 +175,51 @@ def test_static_entry_point_two_slabs_phase_1_then_2(variant):
     assert (np.linalg.norm(got - acc, axis=1) / np.linalg.norm(acc, axis=1)).max() <= 1e-12
 
 
+def test_static_entry_point_under_hip_graph_capture():
+    """What the entry point is for: a caller under HIP graph capture, where hipMalloc is illegal.
+    Two small steps (ping-pong buffers) are captured into one graph through torch's stream
+    capture and replayed three times; the state must equal six direct calls, bit for bit.
+    (The first, un-captured call resolves the array's address on the device.)"""
+    import torch
+    dev = torch.device("cuda", 0)
+    n = 20000
+    p, m = nb.ic_plummer(n, 21)
+    S = nb.round_up(n, 1024)
+
+    def fresh():
+        pos, vel, mass = _slab(p, m, S, dev)
+        return [pos, pos.clone()], vel, mass
+
+    def args(bufs, vel, mass, cur):
+        a = nb.StepArgs()
+        a.pos_cur, a.pos_next, a.mass, a.vel = bufs[cur].data_ptr(), bufs[cur ^ 1].data_ptr(), mass.data_ptr(), vel.data_ptr()
+        a.shard_slots, a.num_shards, a.own_shard, a.own_count = S, 1, 0, n
+        a.j0_begin, a.j0_end = 0, n
+        a.dt, a.G, a.eps2, a.precision, a.variant = 1e-3, nb.G_REFERENCE, 0.0, nb.FP64, nb.VARIANT_SYM
+        return a
+
+    L = nb.lib()
+    # direct: six steps on the current stream
+    bufs, vel, mass = fresh()
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    for k in range(6):
+        nb.check(L.nbody_mi355x_step_f64_static(C.byref(args(bufs, vel, mass, k & 1)), stream))
+    torch.cuda.synchronize(dev)
+    want = (bufs[0].cpu().numpy(), vel.cpu().numpy())
+    # captured: two steps per graph, three replays
+    bufs, vel, mass = fresh()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        cap = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        for k in range(2):
+            nb.check(L.nbody_mi355x_step_f64_static(C.byref(args(bufs, vel, mass, k & 1)), cap))
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize(dev)
+    assert np.array_equal(bufs[0].cpu().numpy(), want[0]) and np.array_equal(vel.cpu().numpy(), want[1])
+    assert not np.array_equal(want[0][:, :n], p[:, :3].T)      # the bodies did move
+
+
 def test_static_entry_point_rejects_what_does_not_fit():
     import torch
     dev = torch.device("cuda", 0)

@@ -3,7 +3,7 @@
 small step for every (bodies, block = 64 * ipt, workgroups per row) of a grid, equal masses, FP64.
 (Round 2 swept entries per workgroup, NBODY_MI355X_SYMW_PER: profiles/r02_wave_tile_sweep.csv; since
 round 3 a row's list is dealt in octets and the knob is the number of workgroups per row.)
-    python tools/sweep_wave_plan.py [sizes] > profiles/r03_wave_tile_sweep.csv"""
+    python tools/sweep_wave_plan.py [sizes] > profiles/r03_wave_tile_sweep.csv      (SWEEP_FP32=1: the FP32 tier)"""
 import os
 import sys
 from pathlib import Path
@@ -25,7 +25,7 @@ for n in SIZES:
         for per in CHUNKS:
             os.environ["NBODY_MI355X_SYMW_CHUNKS"] = str(per)
             try:
-                with nb.Simulation(n, 1e-3, variant=20 + ipt) as sim:
+                with nb.Simulation(n, 1e-3, variant=20 + ipt, precision=nb.FP32 if os.environ.get("SWEEP_FP32") else nb.FP64) as sim:
                     sim.upload(p, m)
                     sim.run(steps, snapshot=False)
                     t = []
