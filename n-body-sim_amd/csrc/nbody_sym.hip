@@ -308,14 +308,23 @@ __device__ __forceinline__ void sum_partials(const SymArgs& sa, int slab, int64_
     z += Cd[2 * S];
     if (sa.q > 0) {
       // wave tiles: was this entry of row I cut between two waves?  Its octets are [8 e, 8 e + 8)
-      // of the row's list; wave k begins at octet k q: the first boundary behind 8 e is that of
-      // wave k = floor(8 e / q) + 1, and it cuts the entry iff it falls before 8 e + 8 (and
+      // of the row's list; wave k begins at octet k q (the first ws waves) or ws q + (k - ws) qb
+      // (those behind them): the first boundary behind 8 e is that of wave k = floor(8 e / q) + 1
+      // (or its like in the second range), and it cuts the entry iff it falls before 8 e + 8 (and
       // inside the row's list: the high rows' lists are shorter by the antipodal tile)
       int dh = sa.d_hi;
       if (2 * dh == sa.nb && I >= sa.nb / 2) dh--;
       const unsigned o = 8u * static_cast<unsigned>(((d - sa.d_lo) << (sa.bshift - 6)) + (jl >> 6));
-      const unsigned k = __umulhi(o, sa.q_magic) + 1u;
-      const unsigned b = k * static_cast<unsigned>(sa.q);
+      const unsigned split = static_cast<unsigned>(sa.ws) * static_cast<unsigned>(sa.q);
+      unsigned k, b;
+      if (o < split) {
+        k = __umulhi(o, sa.q_magic) + 1u;
+        b = k * static_cast<unsigned>(sa.q);
+      } else {
+        const unsigned r = __umulhi(o - split, sa.qb_magic) + 1u;
+        k = static_cast<unsigned>(sa.ws) + r;
+        b = split + r * static_cast<unsigned>(sa.qb);
+      }
       if (b < o + 8u && b < static_cast<unsigned>((dh - sa.d_lo + 1) << (sa.bshift - 6)) * 8u) {
         const double* Cb = sa.Cb + (static_cast<int64_t>(il) * sa.wstride + k) * 192 + (jl & 63);
         x += Cb[0];
@@ -431,6 +440,8 @@ struct Plan {
   int ipt, nbs, nb, D, dsplit, jsplit, jlocal;
   int rchunks;  // R chunks the main launch writes per row (dsplit * jsplit / wave tiles: workgroups per row)
   int cbrows;   // wave tiles: rows of the workspace that hold Cb (second parts of cut entries)
+  int ca;       // wave tiles: chunks of a row whose workgroups are dispatched first (uneven dealing, set_octets); 0: even
+  double rho;   //   ... and the share of a later wave relative to theirs
   int64_t block;      // slots per block
   int64_t bytes;      // preferred workspace: every distance in one batch, capped (kBatchCap)
   int64_t row_bytes;  // 3 * S doubles: one R chunk / one distance of C / the batch accumulator
@@ -466,6 +477,8 @@ double plan_for(const nbody_mi355x_step_args& a, int ipt, Plan* p) {
   if (a.num_shards < 1 || a.shard_slots <= 0 || a.shard_slots % B != 0) return -1.0;
   p->wave = false;
   p->cbrows = 0;
+  p->ca = 0;
+  p->rho = 1.0;
   p->block = B;
   p->ipt = ipt;
   p->nbs = static_cast<int>(a.shard_slots / B);
@@ -528,6 +541,12 @@ double plan_for(const nbody_mi355x_step_args& a, int ipt, Plan* p) {
 // Against the best of the sweep this rule loses 0.5 % on average, 1.7 % at worst over the sizes
 // it decides.  NBODY_MI355X_SYMW_CHUNKS overrides it.
 constexpr int64_t kWaveTileMaxSlots = 262143;  // wave tiles up to here, workgroup tiles beyond
+// Uneven dealing (set_octets): a later wave's share of octets relative to an older wave's, in percent
+// (0: even dealing), from a sweep on the chip (tools/sweep_skew.sh, 10 ... 40 %: flat from 10 to 20,
+// worse above) and from the trace: a SIMD's arbiter serves its older wave first, which then runs at
+// 0.87 of the SIMD's rate whatever its neighbour does; the younger gets the 0.13 that is left.
+constexpr int kSkewPercent = 15;
+constexpr int64_t kSkewMinOctets = 24;  // octets per older wave from which the dealing is uneven
 bool plan_wave(const nbody_mi355x_step_args& a, int ipt, Plan* p) {
   const int64_t B = 64 * ipt;
   if (a.num_shards < 1 || a.shard_slots <= 0 || a.shard_slots % B != 0) return false;
@@ -554,7 +573,27 @@ bool plan_wave(const nbody_mi355x_step_args& a, int ipt, Plan* p) {
                          0.0005 * c - 0.02 / static_cast<double>(rounds) - (wgs < 2 * kCUs ? 0.01 : 0.0);
     if (score > best_score) best = c, best_score = score;
   }
-  if (const int v = env_int("NBODY_MI355X_SYMW_CHUNKS"); v >= 1 && (octets + 4 * v - 1) / (4 * v) >= 8) best = v;
+  p->ca = 0;
+  p->rho = 1.0;
+  // Uneven dealing (see set_octets): one launch of exactly two workgroups per CU, the first
+  // 256 / nbs chunks of every row (dispatched first: the older wave of every SIMD) with the
+  // larger share.  Needs enough octets per SIMD that the smaller share is still >= 8.
+  {
+    int pct = kSkewPercent;
+    if (const char* v = getenv("NBODY_MI355X_SYMW_SKEW"); v != nullptr && v[0] != 0) pct = atoi(v);
+    // (the first ca chunks of every row must fill the chip: 256 / nbs workgroups per row, and no
+    // more than 1/16 of the CUs left without one -- 96 rows would leave 64 CUs to the short items)
+    const int ca = p->nbs <= kCUs ? static_cast<int>(kCUs / p->nbs) : 0;
+    int64_t min_octets = kSkewMinOctets;
+    if (const int v = env_int("NBODY_MI355X_SYMW_SKEW_MIN"); v > 0) min_octets = v;
+    if (pct > 0 && pct < 100 && ca >= 1 && 16 * ca * p->nbs >= 15 * kCUs && a.precision != NBODY_MI355X_FP32 &&
+        octets >= static_cast<int64_t>(4 * ca) * min_octets) {
+      p->ca = ca;
+      p->rho = pct / 100.0;
+      best = 2 * ca;
+    }
+  }
+  if (const int v = env_int("NBODY_MI355X_SYMW_CHUNKS"); v >= 1 && (octets + 4 * v - 1) / (4 * v) >= 8) best = v, p->ca = 0;
   p->rchunks = best;
   p->dsplit = p->jsplit = 1;
   p->jlocal = (ipt + 3) / 4;  // phase 1: the ipt entries of the diagonal tile, one per wave
@@ -642,12 +681,33 @@ hipError_t launch_tiles(const Plan& p, bool fp32, const SymArgs& sa, dim3 grid, 
 // wave tiles: `octets` of a row's list over the 4 * chunks waves of `chunks` workgroups: at
 // least 8 octets per wave (fewer workgroups if need be; returned), and the multiplier the
 // finishing kernels divide by q with -- exact for x q < 2^32 (x: an octet index, < 2^21)
-int set_octets(SymArgs* sa, int64_t octets, int chunks) {
+int set_octets(SymArgs* sa, int64_t octets, int chunks, int old_chunks = 0, double rho = 1.0) {
+  const auto magic = [](int64_t q) { return static_cast<unsigned>((uint64_t{1} << 32) / static_cast<uint64_t>(q)) + 1u; };
+  if (old_chunks > 0 && old_chunks < chunks) {
+    // uneven: the waves of the first old_chunks workgroups of a row take qa octets, the others
+    // qb ~ rho qa (>= 8 both; what the later waves cannot take at 8 each stays with the first)
+    const int64_t ws = 4 * old_chunks, wy = 4 * (chunks - old_chunks);
+    int64_t qa = static_cast<int64_t>((static_cast<double>(octets) + ws + rho * wy - 1) / (ws + rho * wy));
+    int64_t qb = octets > ws * qa ? (octets - ws * qa + wy - 1) / wy : 0;
+    if (qb < 8) {
+      qb = 8;
+      qa = octets > wy * 8 ? (octets - wy * 8 + ws - 1) / ws : 0;
+    }
+    if (qa >= qb) {
+      sa->q = static_cast<int>(qa);
+      sa->q_magic = magic(qa);
+      sa->ws = static_cast<int>(ws);
+      sa->qb = static_cast<int>(qb);
+      sa->qb_magic = magic(qb);
+      return chunks;
+    }
+  }
   while (chunks > 1 && (octets + 4 * chunks - 1) / (4 * chunks) < 8) chunks--;
   int64_t q = (octets + 4 * chunks - 1) / (4 * chunks);
   if (q < 8) q = 8;
-  sa->q = static_cast<int>(q);
-  sa->q_magic = static_cast<unsigned>((uint64_t{1} << 32) / static_cast<uint64_t>(q)) + 1u;
+  sa->q = sa->qb = static_cast<int>(q);
+  sa->q_magic = sa->qb_magic = magic(q);
+  sa->ws = 4 * chunks;
   return chunks;
 }
 
@@ -679,7 +739,8 @@ hipError_t launch(const Plan& p, SymArgs sa, const nbody_mi355x_step_args& a, hi
       const int64_t octets = static_cast<int64_t>(hi - lo + 1) * p.ipt * 8, all = static_cast<int64_t>(sa.D + 1) * p.ipt * 8;
       int chunks = static_cast<int>((p.rchunks * octets + all - 1) / all);
       chunks = chunks < 1 ? 1 : (chunks > p.rchunks ? p.rchunks : chunks);
-      chunks = set_octets(&sa, octets, chunks);
+      // (uneven dealing only where one launch walks the whole list: its two workgroups per CU start together)
+      chunks = only && p.ca > 0 ? set_octets(&sa, octets, p.rchunks, p.ca, p.rho) : set_octets(&sa, octets, chunks);
       grid = dim3(sa.nbs, chunks, 1);
       sa.nR = sa.r_base + chunks;
     }
@@ -791,8 +852,8 @@ int sym_step(const nbody_mi355x_step_args& a, hipStream_t stream) {
   while ((int64_t{1} << sa.bshift) < p.block) sa.bshift++;
   sa.trace = nullptr;
   sa.fast = a.precision == NBODY_MI355X_FP64_FAST ? 1 : 0;
-  sa.q = 0;  // (wave tiles: set per launch, set_octets)
-  sa.q_magic = 0;
+  sa.q = sa.qb = sa.ws = 0;  // (wave tiles: set per launch, set_octets)
+  sa.q_magic = sa.qb_magic = 0;
   sa.wstride = 4 * p.rchunks;
   sa.no_eq = env_int("NBODY_MI355X_SYM_NOEQ") != 0 ? 1 : 0;  // tests: compare the two forms bit for bit
   const hipError_t e = launch(p, sa, a, stream, static_cast<int>(batch), accum);

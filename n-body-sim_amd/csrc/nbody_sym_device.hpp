@@ -38,6 +38,14 @@ struct SymArgs {
   // [k q, (k+1) q) of it -- whole entries in the middle, PARTS of entries at the two ends:
   int q;               // octets per wave, >= 8, so an entry is cut at most once
   unsigned q_magic;    // floor(x / q) = (x * q_magic) >> 32 for every x the finishing kernels form
+  // Uneven dealing (set_octets): the row's first `ws` waves -- those of the workgroups that are
+  // dispatched first, one per CU -- take q octets each, the waves behind them qb <= q: the SIMD's
+  // arbiter serves its oldest wave first, so the second wave of a SIMD only fills the issue
+  // slots the first leaves, and finishes with it only if its share is that much smaller.
+  // Wave k begins at octet k q (k <= ws) or ws q + (k - ws) qb.  Even dealing: ws = all, qb = q.
+  int ws;
+  int qb;              // >= 8
+  unsigned qb_magic;
   double* Cb;          // [nbs][wstride][3][64]: j-side sums of the SECOND part of a cut entry, by
                        // the wave that computed it (the first part goes to C like a whole entry)
   int wstride;         // waves per row in Cb's indexing (4 * chunks of the largest launch)

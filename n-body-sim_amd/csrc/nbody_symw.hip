@@ -98,6 +98,7 @@ __global__ __launch_bounds__(256) void sym_wave_kernel(const SymArgs a) {
     t[0] = wall_clock64();
     t[2] = __builtin_amdgcn_s_getreg((4) | (31 << 11));   // HW_REG_HW_ID
     t[3] = __builtin_amdgcn_s_getreg((20) | (31 << 11));  // HW_REG_XCC_ID
+    t[10] = __builtin_readcyclecounter();                 // shader clock (s_memtime): with t[0], t[1] the clock it ran at
   }
 
   T xi[IPT], yi[IPT], zi[IPT], mi[IPT], ax[IPT], ay[IPT], az[IPT];
@@ -145,7 +146,8 @@ __global__ __launch_bounds__(256) void sym_wave_kernel(const SymArgs a) {
   if (2 * dh == a.nb && I >= a.nb / 2) dh--;  // the antipodal tile belongs to the low rows
   const int n_octets = (dh - a.d_lo + 1) * IPT * 8;
   const int wr = __builtin_amdgcn_readfirstlane(c * 4 + w);  // this wave among the row's
-  int o_begin = wr * a.q, o_end = o_begin + a.q;
+  int o_begin = wr < a.ws ? wr * a.q : a.ws * a.q + (wr - a.ws) * a.qb;
+  int o_end = o_begin + (wr < a.ws ? a.q : a.qb);
   if (o_begin > n_octets) o_begin = n_octets;
   if (o_end > n_octets) o_end = n_octets;
 
@@ -281,6 +283,7 @@ __global__ __launch_bounds__(256) void sym_wave_kernel(const SymArgs a) {
     t[7] = t_store;  //   ... the j-side sums stored
     t[8] = t_done;   // the list is done: what follows is the i-side sums through LDS and the R store
     t[9] = n_done;   // entries (or parts) wave 0 walked
+    t[11] = __builtin_readcyclecounter();
   }
 }
 
@@ -300,7 +303,7 @@ hipError_t launch_one(const SymArgs& sa, dim3 grid, hipStream_t stream) {
 
 // NBODY_MI355X_SYMW_TRACE=FILE (tuning only): every wave-tile launch is followed by a
 // synchronisation and appends one line per workgroup to FILE:
-//   launch  row  chunk  start  end (100 MHz ticks)  HW_ID  XCC_ID  list-begins  sum(stage)  sum(walk)  sum(store)  list-done  entries
+//   launch  row  chunk  start  end (100 MHz ticks)  HW_ID  XCC_ID  list-begins  sum(stage)  sum(walk)  sum(store)  list-done  entries  shader-clocks
 // -- where the dispatcher put each workgroup and when it ran.  Allocates, blocks the host: never
 // set it in a measured run.
 hipError_t launch_wave_tiles_plain(int ipt, bool fp32, const SymArgs& sa, dim3 grid, hipStream_t stream);
@@ -320,9 +323,9 @@ hipError_t launch_wave_tiles(int ipt, bool fp32, const SymArgs& sa_in, dim3 grid
     e = hipMemcpy(h.data(), sa.trace, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
     if (FILE* f = e == hipSuccess ? fopen(path, "a") : nullptr) {
       for (size_t k = 0; k < count; k++)
-        fprintf(f, "%d %zu %zu %llu %llu %llu %llu %llu %llu %llu %llu %llu %llu\n", launch_no, k % grid.x, k / grid.x, h[12 * k],
+        fprintf(f, "%d %zu %zu %llu %llu %llu %llu %llu %llu %llu %llu %llu %llu %llu\n", launch_no, k % grid.x, k / grid.x, h[12 * k],
                 h[12 * k + 1], h[12 * k + 2], h[12 * k + 3], h[12 * k + 4], h[12 * k + 5], h[12 * k + 6], h[12 * k + 7],
-                h[12 * k + 8], h[12 * k + 9]);
+                h[12 * k + 8], h[12 * k + 9], h[12 * k + 11] - h[12 * k + 10]);
       fclose(f);
     }
   }

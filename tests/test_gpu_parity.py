@@ -582,15 +582,15 @@ def test_equal_mass_forms_agree_with_general_form(precision, monkeypatch):
 
 @pytest.mark.parametrize("n", [63, 64, 65, 1023, 1024, 1025, 2047, 2048, 2049, 2305, 2559, 2560, 2561, 4095,
                                4096, 4097, 4353, 5000, 7168, 7169, 8191, 8193, 9217, 10240, 11264, 11265, 12289,
-                               16383, 16385, 20480, 24577, 28672, 32767, 32769, 40960, 48128, 49153, 57344,
-                               65535, 65537, 67585, 131073])
+                               14336, 16383, 16385, 18432, 20480, 24577, 28672, 32767, 32769, 40960, 48128, 49153,
+                               57344, 65535, 65537, 67585, 124928, 131073])
 def test_automatic_plan_at_every_boundary(n):
     """The library's own choice (variant 0) one body either side of everything that switches
     it: one wave for the whole system (64), the wave-per-body kernels' shapes (1024, 2560) and
     their end (NBODY_MI355X_WAVE_MAX_BODIES = 4096, the pair-symmetric kernels beyond), the slot
     rounding (256 / 1024 / 2048 at 8192 and 65 536), the sizes at which the launch model of the
-    wave tiles (csrc/nbody_sym.hip: plan_wave) changes block size or chunking -- powers of two
-    and sizes in between -- and ragged last blocks.  Mixed masses (general form) and equal
+    wave tiles (csrc/nbody_sym.hip: plan_wave) changes block size, chunking or from even to uneven
+    dealing of a row's octets -- powers of two and sizes in between -- and ragged last blocks.  Mixed masses (general form) and equal
     masses (deferred form), 3 small steps."""
     rng = np.random.default_rng(n)
     p, m = nb.ic_plummer(n, 900 + n)

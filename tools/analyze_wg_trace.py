@@ -9,7 +9,7 @@ import sys
 rows = collections.defaultdict(list)
 for ln in open(sys.argv[1]):
     f = ln.split()
-    if len(f) not in (7, 13):
+    if len(f) not in (7, 13, 14):
         continue
     launch, row, chunk, t0, t1, hw, xcc = (int(x) for x in f[:7])
     extra = [int(x) for x in f[7:]]
@@ -37,6 +37,9 @@ for launch, ws in sorted(rows.items()):
           f"ends: first {ends[0]:.1f}, median {ends[len(ends) // 2]:.1f}, last {ends[-1]:.1f} us")
     xcd = collections.Counter(w[4][0] for w in ws)
     print("   workgroups per XCD: " + " ".join(f"{k}:{v}" for k, v in sorted(xcd.items())))
+    ck = sorted(w[5][6] / ((w[3] - w[2]) / 100.0) / 1e3 for w in ws if len(w[5]) > 6 and w[3] > w[2])
+    if ck:   # s_memtime ticks per microsecond of the 100 MHz clock
+        print(f"   shader clock while the workgroups ran: min {ck[0]:.2f} median {ck[len(ck) // 2]:.2f} max {ck[-1]:.2f} GHz")
     ex = [w for w in ws if w[5] and w[5][5] > 0]
     if ex:   # where wave 0's time goes (microseconds, medians over the workgroups)
         med = lambda v: sorted(v)[len(v) // 2] / 100.0
