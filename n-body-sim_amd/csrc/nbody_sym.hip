@@ -546,7 +546,8 @@ constexpr int64_t kWaveTileMaxSlots = 262143;  // wave tiles up to here, workgro
 // worse above) and from the trace: a SIMD's arbiter serves its older wave first, which then runs at
 // 0.87 of the SIMD's rate whatever its neighbour does; the younger gets the 0.13 that is left.
 constexpr int kSkewPercent = 15;
-constexpr int64_t kSkewMinOctets = 24;  // octets per older wave from which the dealing is uneven
+constexpr int kSkewPercentF32 = 25;  // (the packed float walk leaves its neighbour more: best of 15 ... 50 %)
+constexpr int64_t kSkewMinOctets = 20;  // octets per older wave from which the dealing is uneven
 bool plan_wave(const nbody_mi355x_step_args& a, int ipt, Plan* p) {
   const int64_t B = 64 * ipt;
   if (a.num_shards < 1 || a.shard_slots <= 0 || a.shard_slots % B != 0) return false;
@@ -579,15 +580,17 @@ bool plan_wave(const nbody_mi355x_step_args& a, int ipt, Plan* p) {
   // 256 / nbs chunks of every row (dispatched first: the older wave of every SIMD) with the
   // larger share.  Needs enough octets per SIMD that the smaller share is still >= 8.
   {
-    int pct = kSkewPercent;
+    int pct = a.precision == NBODY_MI355X_FP32 ? kSkewPercentF32 : kSkewPercent;
     if (const char* v = getenv("NBODY_MI355X_SYMW_SKEW"); v != nullptr && v[0] != 0) pct = atoi(v);
-    // (the first ca chunks of every row must fill the chip: 256 / nbs workgroups per row, and no
-    // more than 1/16 of the CUs left without one -- 96 rows would leave 64 CUs to the short items)
+    // (the first ca chunks of every row must fill the chip, 256 / nbs workgroups per row: all of it
+    // for a long launch -- 24 576 / 40 960 bodies, 240 of 256 CUs: 0.6 / 1.1 % slower than even dealing
+    // in three or more dispatch rounds -- and at least 15/16 of it for a short one, up to 64 octets
+    // per SIMD, which even dealing cannot spread over rounds -- 10 240 ... 20 480 bodies: +3 ... 7 %)
     const int ca = p->nbs <= kCUs ? static_cast<int>(kCUs / p->nbs) : 0;
     int64_t min_octets = kSkewMinOctets;
     if (const int v = env_int("NBODY_MI355X_SYMW_SKEW_MIN"); v > 0) min_octets = v;
-    if (pct > 0 && pct < 100 && ca >= 1 && 16 * ca * p->nbs >= 15 * kCUs && a.precision != NBODY_MI355X_FP32 &&
-        octets >= static_cast<int64_t>(4 * ca) * min_octets) {
+    const bool fills = ca * p->nbs == kCUs || (16 * ca * p->nbs >= 15 * kCUs && octets * p->nbs <= 64 * 4 * kCUs);
+    if (pct > 0 && pct < 100 && ca >= 1 && fills && octets >= static_cast<int64_t>(4 * ca) * min_octets) {
       p->ca = ca;
       p->rho = pct / 100.0;
       best = 2 * ca;
@@ -625,11 +628,12 @@ bool make_plan(const nbody_mi355x_step_args& a, Plan* p) {
   {
     const int64_t total = a.shard_slots * a.num_shards;
     if (total <= kWaveTileMaxSlots) {
-      // block size by system size (round 3's sweep, with a row's list dealt in octets: 512-body
-      // blocks win from 16 384 bodies up -- 16 384: 104.6 us against 106.9 with 256; 24 576: 215.6 /
-      // 219.8 -- 256-body blocks below -- 12 288: 68.4 / 69.5); a smaller block where the larger
-      // one does not divide the slab
-      for (int ipt = total < 14336 ? 4 : 8; ipt >= 1; ipt /= 2)
+      // block size by system size (round 3's sweeps, a row's list dealt in octets, unevenly where
+      // that applies; tools/sweep_skew_blocks.sh, us per step with 256- / 512-body blocks): 12 288:
+      // 63.0 / 67.0; 13 312: 77.8 / 76.6; 14 336: 87.0 / 84.3; 16 384: 103.5 / 102.1; 18 432: 134.0 /
+      // 127.7 -- 512-body blocks from 13 312 slots; a smaller block where the larger one does not
+      // divide the slab
+      for (int ipt = total < 13312 ? 4 : 8; ipt >= 1; ipt /= 2)
         if (plan_wave(a, ipt, p)) return true;
     }
   }

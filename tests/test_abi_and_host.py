@@ -150,7 +150,7 @@ def test_step_variant_reports_the_kernel_choice_without_a_gpu():
     assert variant_of(500) == nb.VARIANT_WAVE and variant_of(nb.WAVE_MAX_BODIES, big) == nb.VARIANT_WAVE
     assert variant_of(100000) in (1, 2) and variant_of(1048576) == 2          # no workspace: one-sided
     assert variant_of(8192, big) == nb.VARIANT_SYMW4 and variant_of(12288, big) == nb.VARIANT_SYMW4
-    assert variant_of(16384, big) == nb.VARIANT_SYMW8          # 512-body blocks from 14 336 slots (round 3's sweep)
+    assert variant_of(16384, big) == nb.VARIANT_SYMW8          # 512-body blocks from 13 312 slots (round 3's sweeps)
     assert variant_of(1048576, big, precision=nb.FP64_FAST) == nb.VARIANT_SYM8   # the tier changes the arithmetic, not the plan
     assert variant_of(65536, big) == nb.VARIANT_SYMW8 and variant_of(1048576, big) == nb.VARIANT_SYM8
     assert variant_of(65536, big, precision=nb.FP32) == nb.VARIANT_SYMW8 and variant_of(1048576, big, precision=nb.FP32) == nb.VARIANT_SYM8

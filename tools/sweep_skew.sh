@@ -6,5 +6,5 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 SIZES=${1:-10240,12288,16384,20480,24576,32768,49152,65536,98304,131072}
 for pct in ${2:-0 15 20 25 30 40}; do
   echo "== skew $pct"
-  NBODY_MI355X_SYMW_SKEW=$pct timeout -k 10 300 python3 $R/tools/sweep_mid.py --sizes $SIZES --reps 3 || exit 1
+  NBODY_MI355X_SYMW_SKEW=$pct timeout -k 10 300 python3 $R/tools/sweep_mid.py --sizes $SIZES --reps 3 $SWEEP_ARGS || exit 1
 done
