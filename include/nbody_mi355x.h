@@ -68,7 +68,7 @@ typedef enum {
                                1e-13 this library's FP64 path is tested to -- hence a tier of its
                                own.  It changes the pair-symmetric kernels' equal-mass form with
                                2048-body workgroup tiles (from 262 144 slots) and 512-body wave tiles
-                               (from 14 336 slots); every other kernel computes plain FP64. */
+                               (from 13 312 slots); every other kernel computes plain FP64. */
 
 /* Time integrator fused into the step's epilogue.
  * EULER: the reference's forward Euler, v' = v + dt a, r' = r + dt v (OLD v)
@@ -235,7 +235,7 @@ int nbody_mi355x_step_workspace_min_bytes(const nbody_mi355x_step_args* args, in
  * runs on, held until the process ends.  args->workspace / workspace_bytes are ignored.
  * It calls no hipMalloc / hipFree or any other allocating routine.  Layouts whose MINIMUM
  * workspace exceeds the array (one slab: every size up to 124 928 bodies fits,
- * some layouts up to about 170 000 -- nbody_mi355x_step_workspace_min_bytes tells) are rejected with
+ * some layouts up to about 200 000 -- nbody_mi355x_step_workspace_min_bytes tells) are rejected with
  * NBODY_MI355X_ERR_INVALID and a text that names the size needed; so are one-sided variants
  * (they need no scratch: call nbody_mi355x_step_f64) and layouts the pair-symmetric kernels
  * do not apply to (fewer than two blocks of the variant's size; with variant 0 the smallest
