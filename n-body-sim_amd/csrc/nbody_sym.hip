@@ -307,11 +307,13 @@ __device__ __forceinline__ void sum_partials(const SymArgs& sa, int slab, int64_
     y += Cd[S];
     z += Cd[2 * S];
     if (sa.q > 0) {
-      // wave tiles: was this entry of row I cut between two waves?  Its octets are [8 e, 8 e + 8)
-      // of the row's list; wave k begins at octet k q (the first ws waves) or ws q + (k - ws) qb
-      // (those behind them): the first boundary behind 8 e is that of wave k = floor(8 e / q) + 1
-      // (or its like in the second range), and it cuts the entry iff it falls before 8 e + 8 (and
-      // inside the row's list: the high rows' lists are shorter by the antipodal tile)
+      // wave tiles: was this entry of row I cut between waves?  Its octets are [8 e, 8 e + 8) of
+      // the row's list; wave k begins at octet k q (the first ws waves) or ws q + (k - ws) qb
+      // (those behind them).  The first boundary behind 8 e is that of wave k = floor(8 e / q) + 1
+      // (or its like in the second range); every boundary that falls before 8 e + 8 (and inside
+      // the row's list: the high rows' lists are shorter by the antipodal tile) begins a part
+      // whose sums are in Cb[row][that wave].  q >= 8: at most one such part, except among the
+      // later waves of an uneven dealing, whose shares may be smaller than an entry.
       int dh = sa.d_hi;
       if (2 * dh == sa.nb && I >= sa.nb / 2) dh--;
       const unsigned o = 8u * static_cast<unsigned>(((d - sa.d_lo) << (sa.bshift - 6)) + (jl >> 6));
@@ -325,11 +327,14 @@ __device__ __forceinline__ void sum_partials(const SymArgs& sa, int slab, int64_
         k = static_cast<unsigned>(sa.ws) + r;
         b = split + r * static_cast<unsigned>(sa.qb);
       }
-      if (b < o + 8u && b < static_cast<unsigned>((dh - sa.d_lo + 1) << (sa.bshift - 6)) * 8u) {
+      unsigned end = static_cast<unsigned>((dh - sa.d_lo + 1) << (sa.bshift - 6)) * 8u;
+      end = end < o + 8u ? end : o + 8u;
+      for (; b < end; k++) {
         const double* Cb = sa.Cb + (static_cast<int64_t>(il) * sa.wstride + k) * 192 + (jl & 63);
         x += Cb[0];
         y += Cb[64];
         z += Cb[128];
+        b += static_cast<unsigned>(k < static_cast<unsigned>(sa.ws) ? sa.q : sa.qb);
       }
     }
   }
@@ -546,7 +551,9 @@ constexpr int64_t kWaveTileMaxSlots = 262143;  // wave tiles up to here, workgro
 // worse above) and from the trace: a SIMD's arbiter serves its older wave first, which then runs at
 // 0.87 of the SIMD's rate whatever its neighbour does; the younger gets the 0.13 that is left.
 constexpr int kSkewPercent = 15;
-constexpr int kSkewPercentF32 = 25;  // (the packed float walk leaves its neighbour more: best of 15 ... 50 %)
+constexpr int kSkewPercentSmall = 25;  // blocks of up to 256 bodies, and the FP32 tier: fewer independent chains per
+                                       // wave (or packed ones) leave the neighbour more -- best of 10 ... 50 %
+int set_octets(SymArgs* sa, int64_t octets, int chunks, int old_chunks, double rho);
 constexpr int64_t kSkewMinOctets = 20;  // octets per older wave from which the dealing is uneven
 bool plan_wave(const nbody_mi355x_step_args& a, int ipt, Plan* p) {
   const int64_t B = 64 * ipt;
@@ -580,7 +587,7 @@ bool plan_wave(const nbody_mi355x_step_args& a, int ipt, Plan* p) {
   // 256 / nbs chunks of every row (dispatched first: the older wave of every SIMD) with the
   // larger share.  Needs enough octets per SIMD that the smaller share is still >= 8.
   {
-    int pct = a.precision == NBODY_MI355X_FP32 ? kSkewPercentF32 : kSkewPercent;
+    int pct = (a.precision == NBODY_MI355X_FP32 || ipt <= 4) ? kSkewPercentSmall : kSkewPercent;
     if (const char* v = getenv("NBODY_MI355X_SYMW_SKEW"); v != nullptr && v[0] != 0) pct = atoi(v);
     // (the first ca chunks of every row must fill the chip, 256 / nbs workgroups per row: all of it
     // for a long launch -- 24 576 / 40 960 bodies, 240 of 256 CUs: 0.6 / 1.1 % slower than even dealing
@@ -591,9 +598,12 @@ bool plan_wave(const nbody_mi355x_step_args& a, int ipt, Plan* p) {
     if (const int v = env_int("NBODY_MI355X_SYMW_SKEW_MIN"); v > 0) min_octets = v;
     const bool fills = ca * p->nbs == kCUs || (16 * ca * p->nbs >= 15 * kCUs && octets * p->nbs <= 64 * 4 * kCUs);
     if (pct > 0 && pct < 100 && ca >= 1 && fills && octets >= static_cast<int64_t>(4 * ca) * min_octets) {
-      p->ca = ca;
-      p->rho = pct / 100.0;
-      best = 2 * ca;
+      SymArgs probe;  // (the shares must come out as asked: at least 8 octets for an older wave, 2 for a later one)
+      if (set_octets(&probe, octets, 2 * ca, ca, pct / 100.0) == 2 * ca && probe.ws == 4 * ca) {
+        p->ca = ca;
+        p->rho = pct / 100.0;
+        best = 2 * ca;
+      }
     }
   }
   if (const int v = env_int("NBODY_MI355X_SYMW_CHUNKS"); v >= 1 && (octets + 4 * v - 1) / (4 * v) >= 8) best = v, p->ca = 0;
@@ -685,19 +695,21 @@ hipError_t launch_tiles(const Plan& p, bool fp32, const SymArgs& sa, dim3 grid, 
 // wave tiles: `octets` of a row's list over the 4 * chunks waves of `chunks` workgroups: at
 // least 8 octets per wave (fewer workgroups if need be; returned), and the multiplier the
 // finishing kernels divide by q with -- exact for x q < 2^32 (x: an octet index, < 2^21)
-int set_octets(SymArgs* sa, int64_t octets, int chunks, int old_chunks = 0, double rho = 1.0) {
+int set_octets(SymArgs* sa, int64_t octets, int chunks, int old_chunks = 0, double rho = 1.0);
+int set_octets(SymArgs* sa, int64_t octets, int chunks, int old_chunks, double rho) {
   const auto magic = [](int64_t q) { return static_cast<unsigned>((uint64_t{1} << 32) / static_cast<uint64_t>(q)) + 1u; };
   if (old_chunks > 0 && old_chunks < chunks) {
     // uneven: the waves of the first old_chunks workgroups of a row take qa octets, the others
-    // qb ~ rho qa (>= 8 both; what the later waves cannot take at 8 each stays with the first)
+    // qb ~ rho qa: at least 2 (the multiplier above), possibly less than an entry -- an entry among
+    // them is then cut more than once, which the finishing kernels walk (sum_partials)
     const int64_t ws = 4 * old_chunks, wy = 4 * (chunks - old_chunks);
     int64_t qa = static_cast<int64_t>((static_cast<double>(octets) + ws + rho * wy - 1) / (ws + rho * wy));
     int64_t qb = octets > ws * qa ? (octets - ws * qa + wy - 1) / wy : 0;
-    if (qb < 8) {
-      qb = 8;
-      qa = octets > wy * 8 ? (octets - wy * 8 + ws - 1) / ws : 0;
+    if (qb < 2) {
+      qb = 2;
+      qa = octets > wy * 2 ? (octets - wy * 2 + ws - 1) / ws : 0;
     }
-    if (qa >= qb) {
+    if (qa >= qb && qa >= 8) {
       sa->q = static_cast<int>(qa);
       sa->q_magic = magic(qa);
       sa->ws = static_cast<int>(ws);

@@ -44,7 +44,7 @@ struct SymArgs {
   // slots the first leaves, and finishes with it only if its share is that much smaller.
   // Wave k begins at octet k q (k <= ws) or ws q + (k - ws) qb.  Even dealing: ws = all, qb = q.
   int ws;
-  int qb;              // >= 8
+  int qb;              // >= 2: a later wave's share may be less than an entry, which is then cut more than once
   unsigned qb_magic;
   double* Cb;          // [nbs][wstride][3][64]: j-side sums of the SECOND part of a cut entry, by
                        // the wave that computed it (the first part goes to C like a whole entry)
