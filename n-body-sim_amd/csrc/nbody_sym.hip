@@ -553,7 +553,7 @@ constexpr int64_t kWaveTileMaxSlots = 262143;  // wave tiles up to here, workgro
 constexpr int kSkewPercent = 15;
 constexpr int kSkewPercentSmall = 25;  // blocks of up to 256 bodies, and the FP32 tier: fewer independent chains per
                                        // wave (or packed ones) leave the neighbour more -- best of 10 ... 50 %
-int set_octets(SymArgs* sa, int64_t octets, int chunks, int old_chunks, double rho);
+int set_octets(SymArgs* sa, int64_t octets, int chunks, int old_chunks = 0, double rho = 1.0);  // (below)
 constexpr int64_t kSkewMinOctets = 20;  // octets per older wave from which the dealing is uneven
 bool plan_wave(const nbody_mi355x_step_args& a, int ipt, Plan* p) {
   const int64_t B = 64 * ipt;
@@ -695,7 +695,6 @@ hipError_t launch_tiles(const Plan& p, bool fp32, const SymArgs& sa, dim3 grid, 
 // wave tiles: `octets` of a row's list over the 4 * chunks waves of `chunks` workgroups: at
 // least 8 octets per wave (fewer workgroups if need be; returned), and the multiplier the
 // finishing kernels divide by q with -- exact for x q < 2^32 (x: an octet index, < 2^21)
-int set_octets(SymArgs* sa, int64_t octets, int chunks, int old_chunks = 0, double rho = 1.0);
 int set_octets(SymArgs* sa, int64_t octets, int chunks, int old_chunks, double rho) {
   const auto magic = [](int64_t q) { return static_cast<unsigned>((uint64_t{1} << 32) / static_cast<uint64_t>(q)) + 1u; };
   if (old_chunks > 0 && old_chunks < chunks) {
