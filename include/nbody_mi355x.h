@@ -163,7 +163,7 @@ typedef struct {
 
 #define NBODY_MI355X_VARIANT_WAVE  7 /* one-sided, a wave per 1, 2 or 4 bodies: the default for whole
                                         FP64 steps over at most NBODY_MI355X_WAVE_MAX_BODIES slots */
-#define NBODY_MI355X_WAVE_MAX_BODIES 4096
+#define NBODY_MI355X_WAVE_MAX_BODIES 2048
 #define NBODY_MI355X_VARIANT_TINY  8 /* handle API only, at most 64 bodies: a whole big step in
                                         one launch of one wave (the default there); variants
                                         1-7 keep one launch per small step */

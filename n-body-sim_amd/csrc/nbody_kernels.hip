@@ -535,12 +535,15 @@ bool small_applies(const nbody_mi355x_step_args& a, int64_t max_bodies = 4096) {
          a.own_count > 0;
 }
 
-// a wave per IPW bodies: whole steps over one j range of at most NBODY_MI355X_WAVE_MAX_BODIES
-// slots.  Shapes and thresholds from tools/sweep_small.py and tools/sweep_mid.py on MI355X
-// (microseconds per small step, graph-replayed; pair-symmetric wave tiles in brackets):
-// 500 bodies 3.9, 1024 5.1, 2048 9.4 (11.4), 3072 16.6 (14.1), 4096 20.3 (19.2), 5120 39.8
-// (22.1), 6144 46.8 (33.9), 7168 53.7 (35.3) -- above ~4000 bodies the pair-symmetric kernels'
-// halved arithmetic outweighs their fixed cost (two launches, partial sums through HBM).
+// a wave per IPW bodies: whole steps over one j range.  The default up to
+// NBODY_MI355X_WAVE_MAX_BODIES bodies; up to kWaveFallbackBodies where the pair-symmetric kernels
+// have no workspace.  Shapes and thresholds from tools/sweep_mid.py on MI355X (microseconds per
+// small step, graph-replayed; pair-symmetric wave tiles of the best block size in brackets):
+// 500 bodies 3.9, 1024 5.1 (11.3), 2048 9.5 (12.1), 2304 16.6 (11.0), 2560 16.8 (13.2), 3072 16.5
+// (13.7), 4096 20.5 (15.9), 5120 39.8 (19.5) -- above 2048 bodies the pair-symmetric kernels' halved
+// arithmetic outweighs their fixed cost (two launches, partial sums through HBM).  (Round 2 drew
+// the line at 4096 with whole entries per wave; a row's list dealt in octets moved it.)
+constexpr int64_t kWaveFallbackBodies = 4096;
 constexpr int64_t kWaveMaxBodies = NBODY_MI355X_WAVE_MAX_BODIES;
 template <int JPL, int IPW>
 hipError_t launch_wave_t(const nbody_mi355x_step_args& a, hipStream_t stream) {
@@ -690,7 +693,8 @@ using nbody_internal::is_sym_variant;
 // on the result, nbody_mi355x_step_variant reports it.
 static int resolve_variant(const nbody_mi355x_step_args* args) {
   if (is_sym_variant(args->variant)) return nbody_internal::sym_resolve(*args);  // (-1: does not apply)
-  const bool wave_size = small_applies(*args, kWaveMaxBodies) && args->j0_end - args->j0_begin <= kWaveMaxBodies;
+  const bool wave_ok = small_applies(*args, kWaveFallbackBodies) && args->j0_end - args->j0_begin <= kWaveFallbackBodies;
+  const bool wave_size = wave_ok && args->own_count <= kWaveMaxBodies;
   if (args->variant == 0 && !wave_size && args->workspace != nullptr &&
       args->acc_in == nullptr && args->acc_out == nullptr && args->own_count >= kSymMinBodies &&
       args->j0_begin == 0 && args->j1_begin == args->j1_end &&
@@ -703,7 +707,7 @@ static int resolve_variant(const nbody_mi355x_step_args* args) {
     if (nbody_internal::sym_supported(a, &preferred, &least) && least <= a.workspace_bytes)
       return nbody_internal::sym_resolve(a);
   }
-  if (wave_size && (args->variant == 0 || args->variant > 7)) return NBODY_MI355X_VARIANT_WAVE;
+  if (wave_ok && (args->variant == 0 || args->variant > 7)) return NBODY_MI355X_VARIANT_WAVE;
   // a step with acc_in and no j range only integrates sums that were reduced in double: it
   // takes a double build whatever the precision, as the one-slab finish kernel does --
   // narrowing them first would make 1-shard and N-shard FP32 runs differ for nothing

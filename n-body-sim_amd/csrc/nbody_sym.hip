@@ -641,9 +641,11 @@ bool make_plan(const nbody_mi355x_step_args& a, Plan* p) {
       // block size by system size (round 3's sweeps, a row's list dealt in octets, unevenly where
       // that applies; tools/sweep_skew_blocks.sh, us per step with 256- / 512-body blocks): 12 288:
       // 63.0 / 67.0; 13 312: 77.8 / 76.6; 14 336: 87.0 / 84.3; 16 384: 103.5 / 102.1; 18 432: 134.0 /
-      // 127.7 -- 512-body blocks from 13 312 slots; a smaller block where the larger one does not
+      // 127.7 -- 512-body blocks from 13 312 slots; at the small end 64-body blocks up to 2560
+      // slots (2304: 11.0 / 13.3 with 128) and 128-body blocks up to 4608 (3072: 13.7, 64: 13.9; 4096:
+      // 15.9, 256: 18.6; 5120: 21.9 / 19.5 with 256); a smaller block where the larger one does not
       // divide the slab
-      for (int ipt = total < 13312 ? 4 : 8; ipt >= 1; ipt /= 2)
+      for (int ipt = total <= 2560 ? 1 : (total <= 4608 ? 2 : (total < 13312 ? 4 : 8)); ipt >= 1; ipt /= 2)
         if (plan_wave(a, ipt, p)) return true;
     }
   }

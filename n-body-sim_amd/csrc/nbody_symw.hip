@@ -1,5 +1,5 @@
 // nbody_symw.hip -- the pair-symmetric small step with WAVE tiles: the mid-size systems
-// (4097 bodies .. 262 143 slots on a GPU), where a launch of workgroup tiles (nbody_sym.hip)
+// (2049 bodies .. 262 143 slots on a GPU), where a launch of workgroup tiles (nbody_sym.hip)
 // is a few hundred big work items on 1024 SIMDs -- mostly ramp and tail -- and smaller
 // workgroup tiles pay for it with 6 DPP moves per pair instead of per 8.
 //

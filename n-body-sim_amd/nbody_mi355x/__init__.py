@@ -57,7 +57,7 @@ class StepArgs(C.Structure):
 EXCHANGE_NONE, EXCHANGE_PEER_COPIES, EXCHANGE_RCCL = 0, 1, 2
 VARIANT_WAVE, VARIANT_TINY = 7, 8
 STATIC_SCRATCH_BYTES = 134217728   # NBODY_MI355X_STATIC_SCRATCH_BYTES
-WAVE_MAX_BODIES = 4096   # NBODY_MI355X_WAVE_MAX_BODIES: below, whole FP64 steps take the wave kernels
+WAVE_MAX_BODIES = 2048   # NBODY_MI355X_WAVE_MAX_BODIES: below, whole FP64 steps take the wave kernels
 VARIANT_SYM, VARIANT_SYM1, VARIANT_SYM2, VARIANT_SYM4, VARIANT_SYM8 = 10, 11, 12, 14, 18
 VARIANT_SYMW1, VARIANT_SYMW2, VARIANT_SYMW4, VARIANT_SYMW8 = 21, 22, 24, 28   # pair-symmetric, wave tiles
 SYM_VARIANTS = (VARIANT_SYM, VARIANT_SYM1, VARIANT_SYM2, VARIANT_SYM4, VARIANT_SYM8,

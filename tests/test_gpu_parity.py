@@ -133,7 +133,10 @@ def test_fp32_variant_within_1e_4(variant):
     else:
         # the library's own choice: up to NBODY_MI355X_WAVE_MAX_BODIES bodies a step is latency-bound
         # and the double kernels are the fastest way to serve a caller that merely ALLOWS float
-        assert err <= 1e-12
+        s = load_golden("g4_plummer_1024")
+        assert s["particles"].shape[0] <= nb.WAVE_MAX_BODIES
+        _, small = gpu_simulate(s["particles"], s["mass"], 1, 100, float(s["dt"]), precision=nb.FP32)
+        assert rel_pos_err(small[0, :, :3], s["out_cpu"][0, :, :3]) <= 1e-12
         n = 20000                                   # beyond: the float pair-symmetric kernels
         p, m = nb.ic_plummer(n, 77)
         _, ref = ol.simulate(p, m, 1, 10, 1e-3, threads=16)
@@ -580,14 +583,15 @@ def test_equal_mass_forms_agree_with_general_form(precision, monkeypatch):
             assert np.array_equal(b, c) and np.array_equal(fin_b, fin_c)
 
 
-@pytest.mark.parametrize("n", [63, 64, 65, 1023, 1024, 1025, 2047, 2048, 2049, 2305, 2559, 2560, 2561, 4095,
-                               4096, 4097, 4353, 5000, 7168, 7169, 8191, 8193, 9217, 10240, 11264, 11265, 12289,
+@pytest.mark.parametrize("n", [63, 64, 65, 1023, 1024, 1025, 2047, 2048, 2049, 2305, 2559, 2560, 2561, 3000, 4095,
+                               4096, 4097, 4353, 4608, 4609, 5000, 7168, 7169, 8191, 8193, 9217, 10240, 11264, 11265, 12289,
                                14336, 16383, 16385, 18432, 20480, 24577, 28672, 32767, 32769, 40960, 48128, 49153,
                                57344, 65535, 65537, 67585, 124928, 131073])
 def test_automatic_plan_at_every_boundary(n):
     """The library's own choice (variant 0) one body either side of everything that switches
     it: one wave for the whole system (64), the wave-per-body kernels' shapes (1024, 2560) and
-    their end (NBODY_MI355X_WAVE_MAX_BODIES = 4096, the pair-symmetric kernels beyond), the slot
+    their end (NBODY_MI355X_WAVE_MAX_BODIES = 2048, the pair-symmetric kernels beyond, 64- / 128- /
+    256-body wave tiles changing at 2560 and 4608 slots), the slot
     rounding (256 / 1024 / 2048 at 8192 and 65 536), the sizes at which the launch model of the
     wave tiles (csrc/nbody_sym.hip: plan_wave) changes block size, chunking or from even to uneven
     dealing of a row's octets -- powers of two and sizes in between -- and ragged last blocks.  Mixed masses (general form) and equal
@@ -744,7 +748,8 @@ def test_fp32_symmetric_far_from_the_origin_100_steps(scene):
     assert rel_pos_err(out[0, :, :3], ref[0, :, :3]) > 1e-14   # it is the float kernel
 
 
-@pytest.mark.parametrize("n,kw,expect", [(2, {}, nb.VARIANT_TINY), (500, {}, nb.VARIANT_WAVE), (4096, {}, nb.VARIANT_WAVE),
+@pytest.mark.parametrize("n,kw,expect", [(2, {}, nb.VARIANT_TINY), (500, {}, nb.VARIANT_WAVE), (2048, {}, nb.VARIANT_WAVE),
+                                         (2049, {}, nb.VARIANT_SYMW1), (4096, {}, nb.VARIANT_SYMW2),
                                          (8192, {}, nb.VARIANT_SYMW4), (65536, {}, nb.VARIANT_SYMW8),
                                          (300000, {}, nb.VARIANT_SYM8), (300000, {"variant": 2}, 2),
                                          (30000, {"devices": [0, 0]}, nb.VARIANT_SYMW8)])
