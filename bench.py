@@ -208,6 +208,35 @@ def other_configs(nb):
     return out
 
 
+def config5_multi_rank(nb, make_sim, barrier, reduce_max, n, world, rank):
+    """BASELINE config 5 as north_star states it -- uniform cube N = 4 194 304, fp64 and FP32 forces,
+    strong scaling over the ranks of this run -- beside the multi-rank headline: every rank takes
+    part (same sharding, same collectives as the headline), one warm-up step, two timed steps
+    between barriers, the slowest rank's time.  Rank 0 returns the entries; the one-GPU figures of
+    the same scene are in the N = 1 line's `other_configs`."""
+    import time as _time
+    out = {}
+    p, m = nb.ic_uniform_cube(n, 7)
+    for name, code in (("fp64", nb.FP64), ("fp32", nb.FP32)):
+        sim = make_sim(p, m, 1e-4, code)
+        sim.warm_collectives()
+        sim.step()
+        barrier()
+        t0 = _time.perf_counter()
+        for _ in range(2):
+            sim.step()
+        barrier()
+        sec = reduce_max(_time.perf_counter() - t0) / 2
+        del sim
+        g = float(n) * float(n) / sec / 1e9
+        peak = FP64_VECTOR_PEAK_TFLOPS * (2 if name == "fp32" else 1) * world
+        out[f"config5_uniform_cube_n{n}_{name}_{world}gpu"] = {
+            "value": round(g, 1), "unit": "Ginteractions/s", "n_gpus": world, "scaling": "strong",
+            "frac": round(g * FLOP_PER_INTERACTION / 1e3 / peak, 4), "ms_per_step": round(sec * 1e3, 2),
+            "repetitions": 2, "statistic": "mean of two steps, slowest rank"}
+    return out if rank == 0 else None
+
+
 VERIFY_ROWS = 1024
 VERIFY_TOL = {"f64": {"rows": 1e-12, "momentum": 1e-12, "positions": 1e-12},
               "f32": {"rows": 1e-4, "momentum": 1e-5, "positions": 1e-4}}
@@ -458,6 +487,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the other BASELINE configs that the default N=1 run measures beside the headline")
+    ap.add_argument("--config5-bodies", type=int, default=None,
+                    help="rehearsal only: size of the multi-rank config-5 leg (default 4 194 304, run beside the "
+                         "N=1M headline with more than one rank); giving it runs the leg beside any headline size")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
     ap.add_argument("--share-devices", action="store_true",
                     help="rehearsal only: ranks share the visible GPUs (device = local_rank %% device_count)")
@@ -581,6 +613,25 @@ def main():
             verify_failed = v.get("ok") is False
     del ics
 
+    # north_star's other multi-GPU figure (config 5: N = 4M, fp64 and FP32) beside the multi-rank headline
+    multi_other = None
+    if (world > 1 and not args.no_other_configs and args.ic == "plummer" and prec == nb.FP64 and args.variant == 0
+            and integrator == nb.EULER and (n == 1048576 or args.config5_bodies is not None)):
+        # (the headline's handle stays: a few GB per rank of 288)
+        def make_sim(p5, m5, dt5, code):
+            return ShardedNBody(p5, m5, dt5, rank=rank, world=world, device=device,
+                                backend=HipBackend(precision=code, variant=0), overlap=not args.no_overlap)
+
+        def reduce_max(x):
+            t5 = torch.tensor([x], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
+            dist.all_reduce(t5, op=dist.ReduceOp.MAX)
+            return float(t5[0])
+
+        try:
+            multi_other = config5_multi_rank(nb, make_sim, barrier, reduce_max, args.config5_bodies or 4194304, world, rank)
+        except Exception as e:  # noqa: BLE001  (the headline line is not lost to its companion)
+            multi_other = {"config5_error": f"{type(e).__name__}: {e}"} if rank == 0 else None
+
     if rank == 0:
         inter_per_step = float(n) * float(n)
         value = inter_per_step * K / wall / 1e9
@@ -647,6 +698,8 @@ def main():
             del sim                                    # (its 7 GB workspace)
             torch.cuda.empty_cache()
             line["other_configs"] = other_configs(nb)
+        if multi_other:
+            line["other_configs"] = multi_other
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         sys.stdout.flush()

@@ -426,7 +426,7 @@ def test_bench_self_launch_two_ranks_share_the_gpu():
     from pathlib import Path
     repo = Path(__file__).resolve().parent.parent
     r = subprocess.run([sys.executable, str(repo / "bench.py"), "--gpus", "2", "--share-devices", "--backend", "gloo",
-                        "--bodies", "131072", "--steps", "3", "--warmup", "1"],
+                        "--bodies", "131072", "--steps", "3", "--warmup", "1", "--config5-bodies", "262144"],
                        capture_output=True, text=True, timeout=400)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
@@ -434,7 +434,14 @@ def test_bench_self_launch_two_ranks_share_the_gpu():
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["steps"] == 3 and line["scaling"] == "strong"
     assert line["config"]["bodies"] == 131072 and line["value"] > 0
-    assert "cpu_baseline" not in line and "other_configs" not in line     # N = 1 only
+    assert "cpu_baseline" not in line                                      # N = 1 only
+    # north_star's other multi-GPU figure (config 5: the uniform cube, fp64 and FP32) is run by the SAME ranks
+    # beside the headline -- at N = 4M beside the N = 1M headline; a rehearsal size here
+    oc = line["other_configs"]
+    assert set(oc) == {"config5_uniform_cube_n262144_fp64_2gpu", "config5_uniform_cube_n262144_fp32_2gpu"}
+    for e in oc.values():
+        assert e["n_gpus"] == 2 and e["scaling"] == "strong" and e["value"] > 0 and 0 < e["frac"] < 1
+    assert oc["config5_uniform_cube_n262144_fp32_2gpu"]["value"] > oc["config5_uniform_cube_n262144_fp64_2gpu"]["value"]
     # what makes a multi-rank line self-proving: the communicator's own view ...
     c = line["collectives"]
     assert c["world_size_seen"] == 2 and c["backend"] == "gloo" and not c["is_rccl"]
