@@ -37,6 +37,10 @@ With more than one rank (or --force-collectives) the line also proves what ran:
                 steps through the handle API (max relative difference <= 1e-12, SURVEY 8d
                 config 4) or against a --reference-checksum file a one-GPU run wrote.
                 A failed check makes the exit code non-zero.
+  other_configs the other BASELINE configs: on one GPU (N = 1: configs 2, 3, 5, mixed masses, the
+                FP64_FAST tier) or, with more than one rank beside the N = 1M headline, config 5
+                (uniform cube N = 4 194 304, fp64 and FP32) over the SAME ranks -- north_star's second
+                multi-GPU figure; never part of `value`.
 """
 import argparse
 import json
