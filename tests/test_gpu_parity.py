@@ -605,6 +605,37 @@ def test_automatic_plan_at_every_boundary(n):
         assert vec_rel(out[0, :, 6:9], ref[0, :, 6:9]) <= 1e-12
 
 
+@pytest.mark.parametrize("n,precision", [(9216, "fp64"), (12288, "fp64"), (16384, "fp64"), (32768, "fp64"),
+                                         (65536, "fp64"), (131072, "fp64"), (16384, "fp32")])
+def test_uneven_and_even_dealing_of_a_rows_octets_agree(n, precision, monkeypatch):
+    """Wave tiles: where one launch is two workgroups per CU the waves of a row's first workgroups
+    take a larger share of the row's octets than the later ones (csrc/nbody_sym.hip: set_octets;
+    later shares may be less than an entry, which is then cut more than once), otherwise -- and with
+    NBODY_MI355X_SYMW_SKEW=0 -- every wave takes the same.  Both dealings evaluate every pair once:
+    the same accelerations to the rounding of differently grouped sums, both against the oracle's
+    exact sums on sampled rows, and mixed masses through the same cuts."""
+    prec = nb.FP32 if precision == "fp32" else nb.FP64
+    tol = 1e-12 if precision == "fp64" else FP32_ACC_TOL
+    p, m = nb.ic_plummer(n, 300 + n)
+    rows = np.random.default_rng(n).choice(n, 512, replace=False)
+    for masses in (m, m * np.random.default_rng(n + 1).uniform(0.5, 2.0, n)):
+        acc = ol.accel_rows(p, masses, rows, threads=16)
+        scale = np.linalg.norm(acc, axis=1).max()
+        outs = []
+        for skew in (None, "0", "40"):
+            if skew is None:
+                monkeypatch.delenv("NBODY_MI355X_SYMW_SKEW", raising=False)
+            else:
+                monkeypatch.setenv("NBODY_MI355X_SYMW_SKEW", skew)
+            _, out = gpu_simulate(p, masses, 1, 1, 1e-3, precision=prec)
+            outs.append(out[0, :, 6:9])
+            assert np.abs(out[0, rows, 6:9] - acc).max() <= tol * scale
+        for o in outs[1:]:
+            assert np.abs(o - outs[0]).max() <= 2 * tol * scale
+        if precision == "fp64":   # not one launch plan under three names: the sums are grouped differently
+            assert any(not np.array_equal(o, outs[0]) for o in outs[1:])
+
+
 @pytest.mark.parametrize("seed", range(12))
 def test_random_scenes_against_oracle(seed):
     """Seeded random scenes: size, mass spectrum (equal / log-uniform over 6 decades / a few
