@@ -76,7 +76,7 @@ BLOCK_OF_VARIANT = {11: 256, 12: 512, 14: 1024, 18: 2048, 21: 64, 22: 128, 24: 2
 def slab_slots(bodies: int, variant) -> int:
     """Slots of a slab holding `bodies`: slab_slots() of csrc/nbody_internal.h -- whole tiles and
     whole blocks of the pair-symmetric kernels the library would choose or the variant pins."""
-    unit = 2048 if bodies >= 65536 else (1024 if bodies >= 8192 else TILE)
+    unit = 2048 if bodies >= 65536 else (512 if bodies > 12800 else TILE)
     unit = max(unit, BLOCK_OF_VARIANT.get(variant, 0))
     return round_up(bodies, unit)
 
