@@ -30,10 +30,13 @@ inline int64_t block_of_variant(int v) {
 // slots of a slab holding `bodies`: whole tiles, and whole blocks of the pair-symmetric kernels
 // the library would choose -- wave tiles of up to 256 bodies below 13 312 slots, of 512 up to
 // 262 143, workgroup tiles of 2048 beyond (the padding is massless bodies: <= 3 % more slots from
-// 8192 bodies up; round 3: 1024-slot units between 8192 and 65 536 bodies, left from round 1's
-// workgroup tiles, cost up to 12 % more slots -- 8448 bodies ran as 9216) -- or the variant pins
-inline int64_t slab_slots(int64_t bodies, int variant) {
-  int64_t unit = bodies >= 65536 ? 2048 : (bodies > 12800 ? 512 : NBODY_MI355X_TILE);
+// 8192 bodies up; round 3: the 1024- / 2048-slot units of round 1's workgroup tiles from 8192 / 65 536
+// bodies cost up to 12 % more slots -- 8448 bodies ran as 9216) -- or the variant pins
+// (`shards` slabs of this size make the system: the block follows the TOTAL, so a rank's slab of a
+// large system is whole 2048-slot blocks whatever the rank's own count)
+inline int64_t slab_slots(int64_t bodies, int variant, int shards = 1) {
+  const int64_t total = bodies * (shards > 0 ? shards : 1);
+  int64_t unit = total > 261632 ? 2048 : (total > 12800 ? 512 : NBODY_MI355X_TILE);
   if (block_of_variant(variant) > unit) unit = block_of_variant(variant);
   return (bodies + unit - 1) / unit * unit;
 }

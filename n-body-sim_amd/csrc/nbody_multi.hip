@@ -597,7 +597,7 @@ int multi_create(const nbody_mi355x_config& cfg, const int32_t* devices, int32_t
     m->sh[r].begin = base * r + std::min<int64_t>(r, rem);
   }
   const int64_t big = m->sh[0].count;
-  m->S = slab_slots(big, cfg.variant);
+  m->S = slab_slots(big, cfg.variant, num);
   const int64_t S = m->S;
 
   // pair-symmetric kernels: when asked for, or by default for systems they pay off on

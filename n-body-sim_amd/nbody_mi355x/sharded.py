@@ -73,10 +73,12 @@ class _Range:
 BLOCK_OF_VARIANT = {11: 256, 12: 512, 14: 1024, 18: 2048, 21: 64, 22: 128, 24: 256, 28: 512}
 
 
-def slab_slots(bodies: int, variant) -> int:
-    """Slots of a slab holding `bodies`: slab_slots() of csrc/nbody_internal.h -- whole tiles and
-    whole blocks of the pair-symmetric kernels the library would choose or the variant pins."""
-    unit = 2048 if bodies >= 65536 else (512 if bodies > 12800 else TILE)
+def slab_slots(bodies: int, variant, shards: int = 1) -> int:
+    """Slots of a slab holding `bodies`, one of `shards`: slab_slots() of csrc/nbody_internal.h -- whole
+    tiles and whole blocks of the pair-symmetric kernels the library would choose for the WHOLE system
+    or the variant pins."""
+    total = bodies * max(1, shards)
+    unit = 2048 if total > 261632 else (512 if total > 12800 else TILE)
     unit = max(unit, BLOCK_OF_VARIANT.get(variant, 0))
     return round_up(bodies, unit)
 
@@ -200,7 +202,7 @@ class ShardedNBody:
         # with their largest block
         big = max(self.counts)
         variant = getattr(self.backend, "variant", None)
-        self.S = S = slab_slots(big, variant)
+        self.S = S = slab_slots(big, variant, world)
 
         dev = self.device
         if scene is None:

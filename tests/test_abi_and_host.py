@@ -137,7 +137,7 @@ def test_step_variant_reports_the_kernel_choice_without_a_gpu():
     def variant_of(n, workspace_bytes=0, variant=0, precision=nb.FP64, shards=1):
         a = nb.StepArgs()
         a.pos_cur, a.pos_next, a.mass, a.vel = 8, 16, 8, 8    # never dereferenced
-        S = nb.round_up(n, 2048 if n >= 65536 else (512 if n > 12800 else nb.TILE))   # slab_slots(), csrc/nbody_internal.h
+        S = nb.round_up(n, 2048 if n > 261632 else (512 if n > 12800 else nb.TILE))   # slab_slots(), csrc/nbody_internal.h
         a.shard_slots, a.num_shards, a.own_count, a.j0_end = S, shards, n, n
         a.precision, a.variant = precision, variant
         if workspace_bytes:
