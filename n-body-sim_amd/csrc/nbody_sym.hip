@@ -85,7 +85,7 @@ __device__ __forceinline__ void tile_phases(const P2<T>* xy, const P2<T>* zm, T 
     group_steps<IPT, SYM, MODE, T>(xy, zm, gb, lane, xi, yi, zi, mi, ax, ay, az, eps2, c15, c1875, inv_m_ref, 0, 8, &fx,
                                    &fy, &fz);
     if (SYM) {  // the sums are home: lane l holds body l of the group
-      if constexpr (MODE == kDeferred || MODE == kDeferredFast) {
+      if constexpr (MODE == kDeferred || MODE == kDeferredFast || MODE == kRowUnit) {
         fx *= m_ref;
         fy *= m_ref;
         fz *= m_ref;
@@ -194,7 +194,8 @@ __global__ __launch_bounds__(256) void sym_tiles_kernel(const SymArgs a) {
           vzm = P2<T>{static_cast<T>((px[2 * S + idx] - oz) * sc), static_cast<T>(pm[idx] * stage_m)};
         } else {
           vxy = P2<T>{static_cast<T>(px[idx]), static_cast<T>(px[S + idx])};
-          vzm = P2<T>{static_cast<T>(px[2 * S + idx]), static_cast<T>(pm[idx])};
+          vzm = P2<T>{static_cast<T>(px[2 * S + idx]),   // (a uniform row stages m_j / m_ref: kRowUnit)
+                      static_cast<T>(row_uniform ? pm[idx] * inv_m_ref : pm[idx])};
         }
         fill_same = fill_same && (static_cast<T>(pm[idx]) == m_ref);
         xy[q] = vxy;
@@ -853,6 +854,7 @@ int sym_step(const nbody_mi355x_step_args& a, hipStream_t stream) {
   sa.C = sa.Cb + static_cast<int64_t>(p.cbrows) * 3 * a.shard_slots;
   double* accum = a.num_shards == 1 ? sa.C + batch * 3 * a.shard_slots : nullptr;
   sa.S = a.shard_slots;
+  sa.own_count = a.own_count;
   sa.nbs = p.nbs;
   sa.nb = p.nb;
   sa.row0 = a.own_shard * p.nbs;

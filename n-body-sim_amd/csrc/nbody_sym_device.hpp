@@ -19,6 +19,7 @@ struct SymArgs {
   double* C;           // [Db][3][S]  j-side sums of tile (I, I+d) at row d - c_base, indexed by
                        //             OWN row I - row0; Db = distances per batch
   int64_t S;           // slots per slab
+  int64_t own_count;   // bodies in the own slab: its slots from here on are padding (massless, at the origin)
   int nbs;             // blocks per slab = S / B
   int nb;              // blocks in all = num_shards * nbs
   int row0;            // first own block row = own_shard * nbs
@@ -137,6 +138,19 @@ __device__ __forceinline__ void pair_weights(float dx, float dy, float dz, float
   if (WANT_J) *sj = (mi * y0) * y2;
 }
 
+// Wave tiles, own rows: the i side of a PADDING slot (index >= own_count in the own slab) is moved
+// this far out in registers.  Against any real coordinate r^2 ~ 3 * 2^720 (float: 3 * 2^120, in the
+// row's scaled units), y0^3 underflows to exactly 0 and with it every term the slot would add to a
+// real body's sums -- so a row whose REAL bodies have one mass keeps the equal-mass form (the slot's
+// mass, 0, is never looked at there) instead of dropping to the general form for a handful of
+// padding slots: 20 instead of 18 operations per pair for that row, which an evenly dealt launch
+// absorbs and an unevenly dealt one (one round, shares fixed up front) waits for -- 20 000 bodies:
+// 168.9 us against 162.9 before.  Two padding slots meet at separation 0: weight * 0, as a body
+// with itself.
+template <typename T> __device__ __forceinline__ T far_away();
+template <> __device__ __forceinline__ double far_away<double>() { return 0x1p360; }
+template <> __device__ __forceinline__ float far_away<float>() { return 0x1p60f; }
+
 // LDS layout of a staged tile: each group of 64 j bodies takes kGrp = 72 entries, of which
 // entries 64..71 repeat 0..7.  A lane that walks its group from entry r (0..63) can then
 // read 8 consecutive steps at immediate offsets without wrapping, so the inner loop has no
@@ -152,8 +166,11 @@ constexpr int kGrp = 72;
 //              stored: 18 operations per pair.  The benchmark scenes (Plummer sphere,
 //              uniform cube) are equal-mass systems, and so are all but one row of a ring.
 //   kRowUnit   (double) the row has one mass but the staged bodies do not (a padded block,
-//              the ring's planet): the i sums are in units of 1/m_ref, so the i-side weight
-//              is (m_j r^-3) / m_ref; j side as kGeneral.  Rare; 21 operations.
+//              the ring's planet).  The j side is kDeferred's: a body's acceleration does not
+//              depend on its own mass, so sum_i m_ref r^-3 d is right whatever m_j is -- bare
+//              r^-3, times m_ref per sum.  The i side, in units of 1/m_ref, takes r^-3 times
+//              m_j / m_ref, which is what such a row STAGES in the mass slot: 19 operations
+//              (round 3; before, m_j r^-3 / m_ref and m_i r^-3 per pair: 21).
 //   kSameMass  (float) as kDeferred's condition, but the mass stays in the product (r^-3
 //              alone can leave float's range) and one product serves both sides: 19.
 // kDeferred / kRowUnit round once more per sum than kGeneral (the final product with m_ref):
@@ -381,14 +398,16 @@ __device__ __forceinline__ void group_steps(const P2<T>* xy, const P2<T>* zm, in
         const T dx = jxy.a - xi[k];
         const T dy = jxy.b - yi[k];
         const T dz = jzm.a - zi[k];
-        T si, sj = 0;
+        T si = 0, sj = 0;
         if constexpr (MODE == kDeferred) {
           si = sj = pair_r3(dx, dy, dz, eps2, c15, c1875);
         } else if constexpr (MODE == kDeferredFast) {
           if constexpr (sizeof(T) == sizeof(double)) si = sj = pair_r3_fast(dx, dy, dz, eps2, c15);
         } else if constexpr (MODE == kRowUnit) {
-          pair_weights<SYM>(dx, dy, dz, jzm.b, mi[k], eps2, c15, c1875, &si, &sj);
-          si *= inv_m_ref;
+          if constexpr (sizeof(T) == sizeof(double)) {  // (staged: m_j / m_ref)
+            sj = pair_r3(dx, dy, dz, eps2, c15, c1875);
+            si = sj * jzm.b;
+          }
         } else if constexpr (MODE == kSameMass) {
           pair_weights<false>(dx, dy, dz, jzm.b, mi[k], eps2, c15, c1875, &si, &sj);
           sj = si;

@@ -121,6 +121,7 @@ __global__ __launch_bounds__(256) void sym_wave_kernel(const SymArgs a) {
       }
       mi[k] = static_cast<T>(pm[idx]);
       ax[k] = ay[k] = az[k] = 0;
+      if (static_cast<int64_t>(il) * B + idx >= a.own_count) xi[k] = yi[k] = zi[k] = far_away<T>();  // padding: see far_away
     }
   }
   // double: 2^-300 stands in for "no softening" (nbody_device.hpp); float: plain 0 (r^2 == 0
@@ -132,7 +133,8 @@ __global__ __launch_bounds__(256) void sym_wave_kernel(const SymArgs a) {
   const T inv_probe = 1 / m_ref;  // not 0, inf or NaN -- nor so small that 1 / m_ref overflows
   bool row_same = (m_ref != 0) && (m_ref - m_ref == 0) && (inv_probe - inv_probe == 0);
 #pragma unroll
-  for (int k = 0; k < IPT; k++) row_same = row_same && (mi[k] == m_ref);
+  for (int k = 0; k < IPT; k++)  // (padding slots, out of everybody's reach, have no say)
+    row_same = row_same && (mi[k] == m_ref || static_cast<int64_t>(il) * B + k * 64 + lane >= a.own_count);
   const bool row_uniform = __all(row_same) && !a.no_eq;
   const T inv_m_ref = row_uniform ? inv_probe : 0;
   // float: units of the row's scale and (uniform row) mass, as in sym_tiles_kernel
@@ -170,9 +172,17 @@ __global__ __launch_bounds__(256) void sym_wave_kernel(const SymArgs a) {
     if constexpr (!kDouble) {  // relative to the row's origin, narrowed after
       vxy = P2<T>{static_cast<T>((px[idx] - ox) * sc), static_cast<T>((px[S + idx] - oy) * sc)};
       vzm = P2<T>{static_cast<T>((px[2 * S + idx] - oz) * sc), static_cast<T>(pm[idx] * stage_m)};
-    } else {
+    } else {  // (a uniform row stages m_j / m_ref: kRowUnit, nbody_sym_device.hpp)
       vxy = P2<T>{static_cast<T>(px[idx]), static_cast<T>(px[S + idx])};
-      vzm = P2<T>{static_cast<T>(px[2 * S + idx]), static_cast<T>(pm[idx])};
+      vzm = P2<T>{static_cast<T>(px[2 * S + idx]), static_cast<T>(row_uniform ? pm[idx] * inv_m_ref : pm[idx])};
+    }
+    // padding of the OWN slab (known by its index): out of everybody's reach, as on the i side (far_away),
+    // so that the group keeps the equal-mass form; its j-side sums are nobody's
+    const int jl_own = J - a.row0;
+    const bool pad_j = jl_own >= 0 && jl_own < a.nbs && static_cast<int64_t>(jl_own) * B + idx >= a.own_count;
+    if (pad_j) {
+      vxy = P2<T>{far_away<T>(), far_away<T>()};
+      vzm.a = far_away<T>();
     }
     // (the wave's previous group has been read to the end: LDS serves a wave's accesses in order)
     wxy[lane] = vxy;
@@ -181,7 +191,7 @@ __global__ __launch_bounds__(256) void sym_wave_kernel(const SymArgs a) {
       wxy[lane + 64] = vxy;
       wzm[lane + 64] = vzm;
     }
-    const bool equal_mass = __all(static_cast<T>(pm[idx]) == m_ref) && row_uniform;
+    const bool equal_mass = __all(static_cast<T>(pm[idx]) == m_ref || pad_j) && row_uniform;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -201,6 +211,9 @@ __global__ __launch_bounds__(256) void sym_wave_kernel(const SymArgs a) {
           fz *= m_ref;
         } else if (row_uniform) {
           NBODY_GROUP(true, kRowUnit);
+          fx *= m_ref;
+          fy *= m_ref;
+          fz *= m_ref;
         } else {
           NBODY_GROUP(true, kGeneral);
         }
