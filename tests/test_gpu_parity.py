@@ -636,6 +636,20 @@ def test_uneven_and_even_dealing_of_a_rows_octets_agree(n, precision, monkeypatc
             assert any(not np.array_equal(o, outs[0]) for o in outs[1:])
 
 
+def test_random_sizes_masses_and_shards_through_the_librarys_own_plan():
+    """tools/fuzz_plans.py: 40 random systems between 2049 and 150 000 bodies -- every block size of
+    the wave tiles, even and uneven dealing, padded last blocks, mass patterns from one mass to a
+    single heavy body, FP64 and the FP32 tier, one GPU or several shards of the multi-device handle
+    -- against the oracle's trajectory (up to 20 000 bodies) or its exact sums on sampled rows."""
+    import subprocess
+    import sys
+    from pathlib import Path
+    tool = Path(__file__).resolve().parent.parent / "tools" / "fuzz_plans.py"
+    r = subprocess.run([sys.executable, str(tool), "40", "3"], capture_output=True, text=True, timeout=400)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+    assert "40 cases, worst error" in r.stdout
+
+
 @pytest.mark.parametrize("seed", range(12))
 def test_random_scenes_against_oracle(seed):
     """Seeded random scenes: size, mass spectrum (equal / log-uniform over 6 decades / a few
