@@ -125,7 +125,11 @@ typedef struct {
   double* snapshot;       /* if not NULL: DeviceOutputParticle<double>
                              [own_count] = {r', v', a*G} (ref:
                              particle_simulation.h:26-31), device memory      */
-  int64_t shard_slots;    /* multiple of NBODY_MI355X_TILE                     */
+  int64_t shard_slots;    /* multiple of NBODY_MI355X_TILE.  The pair-symmetric
+                             kernels take the largest block that divides it: round
+                             to 512 slots for systems of 12 801 .. 261 632 bodies in
+                             all and to 2048 beyond (the handle API does) to get
+                             the blocks the measurements in DESIGN.md are for     */
   int32_t num_shards;
   int32_t own_shard;
   int64_t own_count;      /* real bodies in the own slab (<= shard_slots)      */
