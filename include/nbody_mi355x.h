@@ -205,6 +205,20 @@ int nbody_mi355x_kdk_drift_f64(const nbody_mi355x_step_args* args, void* stream)
  * kernel, particle_simulation_GPU.cu:60). */
 int nbody_mi355x_step_variant(const nbody_mi355x_step_args* args, int32_t* variant);
 
+/* The launch plan of the pair-symmetric kernels for these args (a whole, unbatched step), for
+ * tests and tuning tools; all 0 where nbody_mi355x_step_variant names a one-sided build.  Read-only,
+ * no launch, runs without a GPU.  plan[NBODY_MI355X_PLAN_FIELDS]:
+ *   [0] family: 1 workgroup tiles, 2 wave tiles     [1] slots per block     [2] block rows of the own slab
+ *   [3] largest block distance D (a row's list: tiles at distances 0 .. D)
+ *   [4] workgroups per block row of the main launch
+ *   wave tiles only -- a row's list is [8] octets (8 rotation steps each), dealt to the row's
+ *   4 * [4] waves: the first [5] waves take [6] octets each, the others [7] (even dealing: [5] = all,
+ *   [7] = [6]); wave k begins at octet k [6] (k <= [5]) or [5] [6] + (k - [5]) [7]
+ *   [9] R rows, [10] Cb rows of the workspace (of 3 * shard_slots doubles each)
+ * No counterpart in the reference (one kernel, one launch shape, particle_simulation_GPU.cu:168-176). */
+#define NBODY_MI355X_PLAN_FIELDS 12
+int nbody_mi355x_step_plan(const nbody_mi355x_step_args* args, int32_t* plan);
+
 /* How many launches of its main (force) kernel a step with these args takes: 1, or -- for the
  * pair-symmetric kernels with a workspace smaller than the unbatched size -- the number of
  * batches the block distances are walked in.  For measurement accounting (work per launch =

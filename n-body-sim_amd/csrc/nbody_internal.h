@@ -35,8 +35,9 @@ inline int64_t block_of_variant(int v) {
 // (`shards` slabs of this size make the system: the block follows the TOTAL, so a rank's slab of a
 // large system is whole 2048-slot blocks whatever the rank's own count)
 inline int64_t slab_slots(int64_t bodies, int variant, int shards = 1) {
-  const int64_t total = bodies * (shards > 0 ? shards : 1);
-  int64_t unit = total > 261632 ? 2048 : (total > 12800 ? 512 : NBODY_MI355X_TILE);
+  const int64_t P = shards > 0 ? shards : 1;
+  int64_t unit = bodies * P > 12800 ? 512 : NBODY_MI355X_TILE;
+  if ((bodies + unit - 1) / unit * unit * P > 262143) unit = 2048;  // beyond the wave tiles (kWaveTileMaxSlots, nbody_sym.hip)
   if (block_of_variant(variant) > unit) unit = block_of_variant(variant);
   return (bodies + unit - 1) / unit * unit;
 }
@@ -51,6 +52,8 @@ int sym_step(const nbody_mi355x_step_args& a, struct ihipStream_t* stream);
 // the concrete variant (NBODY_MI355X_VARIANT_SYM1 .. SYMW8) the plan for these args resolves to, -1: none
 int sym_resolve(const nbody_mi355x_step_args& a);
 int sym_batches(const nbody_mi355x_step_args& a);
+// the launch plan of the pair-symmetric step for these args (nbody_mi355x_step_plan); false: none applies
+bool sym_plan_query(const nbody_mi355x_step_args& a, int32_t* plan);
 // nbody_kernels.hip: `substeps` whole small steps of a system of at most kTinyMaxBodies bodies
 // in ONE launch of one wave (in place on a.pos_cur / a.vel; a.snapshot, if set, receives the
 // last small step's records).  One slab, FP64, no split ranges.

@@ -733,6 +733,23 @@ extern "C" int nbody_mi355x_step_variant(const nbody_mi355x_step_args* args, int
   return NBODY_MI355X_OK;
 }
 
+extern "C" int nbody_mi355x_step_plan(const nbody_mi355x_step_args* args, int32_t* plan) {
+  if (!plan) { set_error("step_plan: null argument"); return NBODY_MI355X_ERR_INVALID; }
+  const int rc = nbody_internal::check_step_args(args);
+  if (rc != NBODY_MI355X_OK) return rc;
+  const int v = resolve_variant(args);
+  for (int k = 0; k < NBODY_MI355X_PLAN_FIELDS; k++) plan[k] = 0;
+  if (v > 0 && is_sym_variant(v)) {
+    nbody_mi355x_step_args a = *args;
+    a.variant = v;
+    if (!nbody_internal::sym_plan_query(a, plan)) {
+      set_error("step_plan: no pair-symmetric plan for variant %d", v);
+      return NBODY_MI355X_ERR_INVALID;
+    }
+  }
+  return NBODY_MI355X_OK;
+}
+
 extern "C" int nbody_mi355x_step_tile_launches(const nbody_mi355x_step_args* args, int32_t* launches) {
   if (!launches) { set_error("step_tile_launches: null argument"); return NBODY_MI355X_ERR_INVALID; }
   const int rc = nbody_internal::check_step_args(args);

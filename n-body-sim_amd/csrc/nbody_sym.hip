@@ -799,6 +799,32 @@ int sym_resolve(const nbody_mi355x_step_args& a) {
   return (p.wave ? 20 : 10) + p.ipt;  // NBODY_MI355X_VARIANT_SYMW* / _SYM*
 }
 
+// nbody_mi355x_step_plan: the plan of a whole, unbatched step (phase 0) as launch() would set it up
+bool sym_plan_query(const nbody_mi355x_step_args& a, int32_t* out) {
+  Plan p;
+  if (!make_plan(a, &p)) return false;
+  for (int k = 0; k < NBODY_MI355X_PLAN_FIELDS; k++) out[k] = 0;
+  out[0] = p.wave ? 2 : 1;
+  out[1] = static_cast<int32_t>(p.block);
+  out[2] = p.nbs;
+  out[3] = p.D;
+  out[9] = p.jlocal + p.rchunks;
+  out[10] = p.cbrows;
+  if (p.wave) {
+    const int64_t octets = static_cast<int64_t>(p.D + 1) * p.ipt * 8;
+    SymArgs sa;
+    const int chunks = p.ca > 0 ? set_octets(&sa, octets, p.rchunks, p.ca, p.rho) : set_octets(&sa, octets, p.rchunks);
+    out[4] = chunks;
+    out[5] = sa.ws;
+    out[6] = sa.q;
+    out[7] = sa.qb;
+    out[8] = static_cast<int32_t>(octets);
+  } else {
+    out[4] = p.dsplit * p.jsplit;
+  }
+  return true;
+}
+
 // launches of the tile kernel a whole step (phase 0 or 2) takes with this workspace: the
 // iterations of the batch loop in launch(); 0 if the plan or the workspace does not apply
 int sym_batches(const nbody_mi355x_step_args& a) {

@@ -57,6 +57,7 @@ class StepArgs(C.Structure):
 EXCHANGE_NONE, EXCHANGE_PEER_COPIES, EXCHANGE_RCCL = 0, 1, 2
 VARIANT_WAVE, VARIANT_TINY = 7, 8
 STATIC_SCRATCH_BYTES = 134217728   # NBODY_MI355X_STATIC_SCRATCH_BYTES
+PLAN_FIELDS = 12          # NBODY_MI355X_PLAN_FIELDS
 WAVE_MAX_BODIES = 2048   # NBODY_MI355X_WAVE_MAX_BODIES: below, whole FP64 steps take the wave kernels
 VARIANT_SYM, VARIANT_SYM1, VARIANT_SYM2, VARIANT_SYM4, VARIANT_SYM8 = 10, 11, 12, 14, 18
 VARIANT_SYMW1, VARIANT_SYMW2, VARIANT_SYMW4, VARIANT_SYMW8 = 21, 22, 24, 28   # pair-symmetric, wave tiles
@@ -83,6 +84,7 @@ SYMBOLS = {
     "nbody_mi355x_step_f64_static": (C.c_int, [C.POINTER(StepArgs), _P]),
     "nbody_mi355x_kdk_drift_f64": (C.c_int, [C.POINTER(StepArgs), _P]),
     "nbody_mi355x_step_tile_launches": (C.c_int, [C.POINTER(StepArgs), C.POINTER(C.c_int32)]),
+    "nbody_mi355x_step_plan": (C.c_int, [C.POINTER(StepArgs), C.POINTER(C.c_int32)]),
     "nbody_mi355x_step_variant": (C.c_int, [C.POINTER(StepArgs), C.POINTER(C.c_int32)]),
     "nbody_mi355x_step_workspace_bytes": (C.c_int, [C.POINTER(StepArgs), C.POINTER(C.c_int64)]),
     "nbody_mi355x_step_workspace_min_bytes": (C.c_int, [C.POINTER(StepArgs), C.POINTER(C.c_int64)]),

@@ -77,8 +77,10 @@ def slab_slots(bodies: int, variant, shards: int = 1) -> int:
     """Slots of a slab holding `bodies`, one of `shards`: slab_slots() of csrc/nbody_internal.h -- whole
     tiles and whole blocks of the pair-symmetric kernels the library would choose for the WHOLE system
     or the variant pins."""
-    total = bodies * max(1, shards)
-    unit = 2048 if total > 261632 else (512 if total > 12800 else TILE)
+    shards = max(1, shards)
+    unit = 512 if bodies * shards > 12800 else TILE
+    if round_up(bodies, unit) * shards > 262143:   # beyond the wave tiles: whole 2048-slot blocks
+        unit = 2048
     unit = max(unit, BLOCK_OF_VARIANT.get(variant, 0))
     return round_up(bodies, unit)
 

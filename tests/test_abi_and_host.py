@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 import nbody_mi355x as nb
-from nbody_mi355x.sharded import shard_counts
+from nbody_mi355x.sharded import shard_counts, slab_slots
 
 REPO = Path(__file__).resolve().parent.parent
 
@@ -137,7 +137,7 @@ def test_step_variant_reports_the_kernel_choice_without_a_gpu():
     def variant_of(n, workspace_bytes=0, variant=0, precision=nb.FP64, shards=1):
         a = nb.StepArgs()
         a.pos_cur, a.pos_next, a.mass, a.vel = 8, 16, 8, 8    # never dereferenced
-        S = nb.round_up(n, 2048 if n > 261632 else (512 if n > 12800 else nb.TILE))   # slab_slots(), csrc/nbody_internal.h
+        S = slab_slots(n, 0)   # csrc/nbody_internal.h and its mirror
         a.shard_slots, a.num_shards, a.own_count, a.j0_end = S, shards, n, n
         a.precision, a.variant = precision, variant
         if workspace_bytes:
@@ -237,3 +237,83 @@ def test_step_tile_launches_counts_the_distance_batches():
     assert launches(65536, preferred(65536)) == 1
     assert launches(65536, preferred(65536) // 2) >= 2
     assert launches(1 << 22, preferred(1 << 22)) >= 8
+
+
+def _plan(n, shards=1, variant=0, precision=None, own_shard=0):
+    import ctypes as C
+    from nbody_mi355x.sharded import shard_counts, slab_slots
+    counts, _ = shard_counts(n, shards)
+    a = nb.StepArgs()
+    a.pos_cur, a.pos_next, a.mass, a.vel = 8, 16, 8, 8    # never dereferenced
+    S = slab_slots(max(counts), variant, shards)
+    a.shard_slots, a.num_shards, a.own_shard, a.own_count = S, shards, own_shard, counts[own_shard]
+    a.j0_end = S * shards
+    a.variant = variant
+    a.precision = nb.FP64 if precision is None else precision
+    a.workspace, a.workspace_bytes = 8, 1 << 40
+    out = (C.c_int32 * nb.PLAN_FIELDS)()
+    nb.check(nb.lib().nbody_mi355x_step_plan(C.byref(a), out))
+    return list(out), S
+
+
+def test_wave_tile_plans_deal_every_octet_once_and_every_cut_part_is_found():
+    """nbody_mi355x_step_plan (host logic, no GPU): over sizes from the wave tiles' first to their
+    last, one to eight slabs, both precisions -- the shares the plan deals (csrc/nbody_sym.hip:
+    plan_wave, set_octets) cover a row's list exactly once, respect their minima (an older wave >= 8
+    octets, a later one >= 2), and the rule by which the finishing kernels find the parts of a cut
+    entry (sum_partials: first boundary behind the entry's start by one division, then boundary by
+    boundary) names exactly the waves that begin inside the entry."""
+    sizes = [2049, 2305, 2560, 3000, 4096, 4609, 5000, 8192, 9000, 9216, 10000, 12288, 12800, 12801, 13312, 15000,
+             16384, 18432, 20000, 24576, 30000, 32768, 40960, 49152, 50000, 65536, 70000, 98304, 100000, 124928,
+             131072, 200000, 261632]
+    seen_uneven = seen_multicut = 0
+    for n in sizes:
+        for shards, prec in ((1, nb.FP64), (1, nb.FP32), (2, nb.FP64), (3, nb.FP64), (8, nb.FP64)):
+            if n // shards < 300:
+                continue
+            # (several slabs: the drivers ask for the pair-symmetric family by name, as the handles do)
+            p, S = _plan(n, shards, variant=0 if shards == 1 else nb.VARIANT_SYM, precision=prec)
+            family, block, rows, D, chunks, ws, q, qb, octets, r_rows, cb_rows = p[:11]
+            if S * shards > 262143:       # several slabs, each rounded up: past the wave tiles' last size
+                assert family == 1 and S % 2048 == 0
+                continue
+            assert family == 2, (n, shards, p)
+            assert S % block == 0 and rows == S // block and D == rows * shards // 2
+            assert octets == (D + 1) * (block // 64) * 8
+            waves = 4 * chunks
+            assert 0 < ws <= waves and q >= 8 and 2 <= qb <= q
+            if ws == waves:
+                assert qb == q                                    # even dealing
+            else:
+                seen_uneven += 1
+                assert ws * 2 == waves and rows * (ws // 4) <= 256 and 16 * rows * (ws // 4) >= 15 * 256
+            begins = [k * q if k <= ws else ws * q + (k - ws) * qb for k in range(waves + 1)]
+            assert begins[-1] >= octets and begins[-1] - octets < 4 * q + 4 * qb    # the list is covered; at most a workgroup's worth to spare
+            assert r_rows >= chunks and cb_rows * 3 * S >= rows * waves * 192    # every wave has its Cb part's room
+            # the finishing kernels' rule against brute force, for the low rows' list and the high rows' (one tile shorter)
+            for n_oct in (octets, octets - (block // 64) * 8 if (rows * shards) % 2 == 0 else octets):
+                for o in range(0, n_oct, 8):
+                    brute = [k for k in range(1, waves) if o < begins[k] < min(o + 8, n_oct)]
+                    split = ws * q
+                    if o < split:
+                        k = o // q + 1
+                        b = k * q
+                    else:
+                        r = (o - split) // qb + 1
+                        k, b = ws + r, split + r * qb
+                    found = []
+                    while b < min(o + 8, n_oct):
+                        found.append(k)
+                        b += q if k < ws else qb
+                        k += 1
+                    assert found == brute, (n, shards, o, found, brute)
+                    seen_multicut += len(found) > 1
+    assert seen_uneven >= 10 and seen_multicut > 0   # both kinds of dealing and entries cut more than once were met
+    # the named cases of DESIGN.md 3.2
+    p, _ = _plan(16384)
+    assert p[1] == 512 and p[4] == 16 and p[5] == 32 and p[6] > 3 * p[7]
+    p, _ = _plan(49152)
+    assert p[5] == 4 * p[4]                                # 96 rows do not fill the chip with their first workgroups: even
+    p, _ = _plan(1048576)
+    assert p[0] == 1 and p[1] == 2048
+    assert _plan(1000)[0][0] == 0                          # one-sided: no plan

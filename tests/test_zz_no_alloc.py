@@ -34,7 +34,8 @@ def _one_step(entry, p, m, dt, *, workspace, precision=nb.FP64):
     import torch
     dev = torch.device("cuda", 0)
     n = p.shape[0]
-    S = nb.round_up(n, 2048 if n > 261632 else (512 if n > 12800 else nb.TILE))   # slab_slots(), csrc/nbody_internal.h
+    from nbody_mi355x.sharded import slab_slots
+    S = slab_slots(n, 0)   # csrc/nbody_internal.h and its mirror
     pos, vel, mass = _slab(p, m, S, dev)
     nxt = torch.zeros_like(pos)
     snap = torch.full((n, 9), np.nan, dtype=torch.float64, device=dev)
